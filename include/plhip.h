@@ -1,0 +1,142 @@
+/*
+ * plhip.h — C ABI of the MI355X (gfx950) INT8 conv / depthwise / fc / calib backend.
+ *
+ * This is the drop-in boundary underneath the TARGET(kHIP)/PRECISION(kInt8) kernel classes in
+ * paddle-lite_amd/lite/kernels/hip/ (which mirror lite/kernels/arm/{conv,fc,calib}_compute.cc of the
+ * reference).  Each entry point names the reference interface it replaces (paths relative to the
+ * reference tree).  Conventions:
+ *   - every data pointer is a DEVICE pointer unless the name says host; the caller owns all buffers,
+ *     the library never frees caller memory and allocates nothing inside a launch function;
+ *   - calls are asynchronous on the context's HIP stream; plhip_stream_sync() waits;
+ *   - return 0 on success, a negative plhip_status otherwise; the library never aborts (the C++
+ *     kernel layer turns non-zero into LOG(FATAL), like CUDA_CALL in lite/backends/cuda/cuda_utils.h);
+ *   - one plhip_ctx per host thread and GPU, not shared between threads
+ *     (shape of lite/backends/cuda/context.h:35-140).
+ * Tensors are dense NCHW; activations/weights int8, bias/scale fp32.  No torch types here.
+ */
+#ifndef PLHIP_H_
+#define PLHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  PLHIP_OK = 0,
+  PLHIP_ERR_INVALID = -1,     /* bad argument / inconsistent descriptor */
+  PLHIP_ERR_HIP = -2,         /* a HIP runtime call failed (see plhip_last_error) */
+  PLHIP_ERR_UNSUPPORTED = -3, /* configuration outside the implemented paths */
+  PLHIP_ERR_WORKSPACE = -4,   /* workspace missing or too small */
+  PLHIP_ERR_NO_DEVICE = -5    /* no HIP device / device is not gfx950 */
+} plhip_status;
+
+/* Output kind.  I32_ACC exists for the bit-exact accumulator check only. */
+typedef enum { PLHIP_OUT_I32_ACC = 0, PLHIP_OUT_F32 = 1, PLHIP_OUT_I8 = 2 } plhip_out_kind;
+
+/* Activation codes == lite_api::ActivationType, lite/api/paddle_place.h:101-105. */
+typedef enum { PLHIP_ACT_NONE = 0, PLHIP_ACT_RELU = 1, PLHIP_ACT_RELU6 = 2, PLHIP_ACT_LEAKY_RELU = 4 } plhip_act;
+
+/* The kernel's whole shape contract == the fields of operators::ConvParam the ARM kernels read
+ * (lite/operators/op_params.h:446-502): x dims, filter dims (OIHW, I = cin/groups), paddings
+ * {top,bottom,left,right}, strides {h,w}, dilations {h,w}, groups, activation_param. */
+typedef struct {
+  int n, cin, h, w;
+  int cout, kh, kw;
+  int pad[4];
+  int stride[2];
+  int dil[2];
+  int groups;
+  int act;         /* plhip_act */
+  float act_alpha; /* relu6: clip coefficient (already divided by out_scale for int8-out,
+                      conv_gemmlike.cc:259-263); leaky: negative slope */
+} plhip_conv_desc;
+
+typedef struct plhip_ctx plhip_ctx;
+
+/* ---- context / memory: replaces TargetWrapper<kCUDA> + CUDAContext for the new target
+ *      (lite/backends/cuda/target_wrapper.h:27-85, lite/backends/cuda/context.h:35-140,
+ *       lite/core/memory.{h,cc} TargetMalloc/TargetFree/TargetCopy). ---- */
+int plhip_device_count(void);
+plhip_status plhip_ctx_create(int device_id, plhip_ctx** out);
+/* Adopt an existing hipStream_t (e.g. the caller's framework stream); not destroyed with the ctx. */
+plhip_status plhip_ctx_create_on_stream(int device_id, void* hip_stream, plhip_ctx** out);
+void plhip_ctx_destroy(plhip_ctx* ctx);
+void* plhip_ctx_stream(plhip_ctx* ctx);
+const char* plhip_last_error(plhip_ctx* ctx);
+plhip_status plhip_malloc(plhip_ctx* ctx, size_t bytes, void** dev_ptr);
+plhip_status plhip_free(plhip_ctx* ctx, void* dev_ptr);
+plhip_status plhip_memcpy_h2d(plhip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+plhip_status plhip_memcpy_d2h(plhip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+plhip_status plhip_memcpy_d2d(plhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+plhip_status plhip_memset(plhip_ctx* ctx, void* dst_dev, int value, size_t bytes);
+plhip_status plhip_stream_sync(plhip_ctx* ctx);
+/* hipEvent timing on the context's stream (DeviceTimer<kCUDA> analogue, lite/core/profile/timer.h:127-158). */
+plhip_status plhip_event_create(plhip_ctx* ctx, void** event);
+plhip_status plhip_event_record(plhip_ctx* ctx, void* event);
+plhip_status plhip_event_elapsed_ms(plhip_ctx* ctx, void* start, void* stop, float* ms);
+plhip_status plhip_event_destroy(plhip_ctx* ctx, void* event);
+
+/* ---- dense / grouped conv2d ----
+ * Replaces: GemmLikeConv / DirectConv / WinogradConv <kInt8,*>::Run (lite/kernels/arm/conv_gemmlike.cc:
+ * 325-462, conv_direct.cc:110-239, conv_winograd.cc:224-475) -> conv1x1s1_gemm_int8 / conv_im2col_gemm_int8
+ * (lite/backends/arm/math/conv_impl.cc:260-331, 490-598) -> gemm_prepack_int8 (gemm_prepacked_int8.cc:
+ * 5263-5457) with its fused epilogue (:643-796).
+ *
+ * Weight pre-pack replaces prepackA_int8 (gemm_prepacked_int8.cc:109-224) / trans_gemm_weights<kInt8>
+ * (conv_block_utils.h:65-73): OIHW int8 -> per-group MFMA A-fragment order, zero padded. */
+size_t plhip_conv_packed_weight_bytes(const plhip_conv_desc* d);
+plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d,
+                                     const int8_t* w_oihw, void* w_packed);
+/* Scratch for the im2col variant (0 for 1x1 s1 p0); replaces ctx.workspace_data (conv_gemmlike.cc:131). */
+size_t plhip_conv_workspace_bytes(const plhip_conv_desc* d);
+/* scale/bias: folded per-output-channel fp32 arrays of length cout; bias may be NULL
+ * (treated as zeros).  y: int32 / float / int8 NCHW according to `out`.  For PLHIP_OUT_I32_ACC scale,
+ * bias and activation are ignored.  Name of the path taken (kernel_func_name analogue,
+ * conv_gemmlike.cc:384): plhip_conv_impl_name(). */
+plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x,
+                               const void* w_packed, const float* scale, const float* bias, void* y,
+                               plhip_out_kind out, void* workspace, size_t workspace_bytes);
+const char* plhip_conv_impl_name(const plhip_conv_desc* d);
+
+/* ---- depthwise conv (groups == cin == cout) ----
+ * Replaces: DepthwiseConv<kInt8,*>::Run (lite/kernels/arm/conv_depthwise.cc:357-446) ->
+ * conv_depthwise_3x3_int8_{fp32,int8} / conv_depthwise_5x5_int8_{fp32,int8}
+ * (lite/backends/arm/math/conv_impl.cc:798-1184).  Weights are the raw OIHW [C,1,kh,kw] filter
+ * (no re-layout needed on this target; cf. conv_trans_weights_numc, conv_block_utils.h:89). */
+plhip_status plhip_depthwise_conv_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x,
+                                       const int8_t* w_oihw, const float* scale, const float* bias,
+                                       void* y, plhip_out_kind out);
+
+/* ---- fc ----
+ * Replaces: FcCompute<kInt8,*>::Run (lite/kernels/arm/fc_compute.cc:229-344) -> gemm_s8 / gemv_int8
+ * (lite/backends/arm/math/gemm_s8.cc:23-47, gemv_arm_int8.cc:701-760).
+ * x [m,k] int8 row-major; w [k,n] int8 (Paddle "mul" layout); scale/bias per output column n.
+ * Pre-pack ([k/4][n][4], zero padded) replaces the weight transpose of fc_compute.cc:53-62. */
+size_t plhip_fc_packed_weight_bytes(int k, int n);
+plhip_status plhip_pack_fc_weights(plhip_ctx* ctx, int k, int n, const int8_t* w_kn, void* w_packed);
+plhip_status plhip_fc_int8(plhip_ctx* ctx, int m, int k, int n, const int8_t* x, const void* w_packed,
+                           const float* scale, const float* bias, int relu, void* y, plhip_out_kind out);
+
+/* ---- calib (graph-edge precision casts) ----
+ * Replaces: CalibComputeFp32ToInt8 / Int8ToFp32 (lite/kernels/arm/calib_compute.cc:25-57) ->
+ * fp32_to_int8 / int8_to_fp32 (lite/backends/arm/math/type_trans.cc:34-187, 268-371), single scale. */
+plhip_status plhip_calib_f32_to_i8(plhip_ctx* ctx, const float* x, int8_t* y, float scale, int64_t count);
+plhip_status plhip_calib_i8_to_f32(plhip_ctx* ctx, const int8_t* x, float* y, float scale, int64_t count);
+
+/* ---- fp32 glue ops of the MobileNet graph kept on device ----
+ * Replaces: PoolCompute global-avg (lite/backends/arm/math/pooling.cc:1006-) and SoftmaxCompute
+ * (lite/backends/arm/math/softmax.cc) for the tail pool2d -> calib -> fc -> softmax. */
+plhip_status plhip_global_avg_pool_f32(plhip_ctx* ctx, const float* x, int nc, int spatial, float* y);
+plhip_status plhip_softmax_f32(plhip_ctx* ctx, const float* x, int rows, int cols, float* y);
+
+/* ---- introspection used by tests: operand-layout self-check of the MFMA tile on this device.
+ * Runs a tiny known-answer GEMM through the MFMA path; returns PLHIP_OK iff bit-exact. ---- */
+plhip_status plhip_selftest(plhip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLHIP_H_ */

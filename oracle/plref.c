@@ -1,0 +1,257 @@
+/*
+ * plref.c — CPU oracle (TEST INFRASTRUCTURE ONLY; see plref.h header comment).
+ *
+ * Plain-C restatement of the reference's INT8 conv/GEMM/FC/calib algorithm.  Not used by,
+ * linked into, or loaded from the product path.  Each function cites the reference lines it
+ * follows (paths relative to the reference tree root).
+ */
+#include "plref.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* lite/tests/math/conv_int8_compute_test.cc:67-88 */
+void plref_conv_out_dims(const plref_conv_shape* s, int* oh, int* ow) {
+  int keh = s->dil[0] * (s->kh - 1) + 1;
+  int kew = s->dil[1] * (s->kw - 1) + 1;
+  *oh = (s->h + s->pad[0] + s->pad[1] - keh) / s->stride[0] + 1;
+  *ow = (s->w + s->pad[2] + s->pad[3] - kew) / s->stride[1] + 1;
+}
+
+/* lite/tests/utils/naive_math_impl.h:393-425 — same loop nest and index math; bias/activation
+ * are applied later by the float epilogue (the ARM kernels never add bias in int32). */
+void plref_conv2d_i8_acc(const plref_conv_shape* s, const int8_t* x, const int8_t* w, int32_t* acc) {
+  int oh, ow;
+  plref_conv_out_dims(s, &oh, &ow);
+  const int g = s->groups;
+  const int ocg = s->cout / g;
+  const int icg = s->cin / g;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < s->n; ++n) {
+    for (int oc_all = 0; oc_all < s->cout; ++oc_all) {
+      const int grp = oc_all / ocg;
+      for (int y = 0; y < oh; ++y) {
+        for (int xo = 0; xo < ow; ++xo) {
+          int32_t sum = 0;
+          for (int ic = 0; ic < icg; ++ic) {
+            for (int r = 0; r < s->kh; ++r) {
+              const int ih = y * s->stride[0] - s->pad[0] + r * s->dil[0];
+              if (ih < 0 || ih >= s->h) continue;
+              for (int q = 0; q < s->kw; ++q) {
+                const int iw = xo * s->stride[1] - s->pad[2] + q * s->dil[1];
+                if (iw < 0 || iw >= s->w) continue;
+                const int64_t iidx = (((int64_t)n * s->cin + grp * icg + ic) * s->h + ih) * s->w + iw;
+                const int64_t widx = (((int64_t)oc_all * icg + ic) * s->kh + r) * s->kw + q;
+                sum += (int32_t)x[iidx] * (int32_t)w[widx];
+              }
+            }
+          }
+          acc[(((int64_t)n * s->cout + oc_all) * oh + y) * ow + xo] = sum;
+        }
+      }
+    }
+  }
+}
+
+/* lite/backends/arm/math/conv_impl.cc:103-153 — K x N row-major, K = c*kh*kw + r*kw + q. */
+void plref_im2col_i8(const int8_t* x, int cin_g, int h, int w, int kh, int kw, const int pad[4],
+                     const int stride[2], const int dil[2], int oh, int ow, int8_t* col) {
+  const int n = oh * ow;
+  for (int c = 0; c < cin_g; ++c) {
+    for (int r = 0; r < kh; ++r) {
+      for (int q = 0; q < kw; ++q) {
+        int8_t* dst = col + (int64_t)((c * kh + r) * kw + q) * n;
+        for (int y = 0; y < oh; ++y) {
+          const int ih = y * stride[0] - pad[0] + r * dil[0];
+          for (int xo = 0; xo < ow; ++xo) {
+            const int iw = xo * stride[1] - pad[2] + q * dil[1];
+            int8_t v = 0;
+            if (ih >= 0 && ih < h && iw >= 0 && iw < w) v = x[((int64_t)c * h + ih) * w + iw];
+            dst[y * ow + xo] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+/* lite/tests/utils/naive_math_impl.h:246-295 with trans_a = trans_b = false, alpha 1, beta 0. */
+void plref_gemm_i8_acc(int m, int n, int k, const int8_t* a, const int8_t* b, int32_t* c) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < m; ++i) {
+    int32_t* crow = c + (int64_t)i * n;
+    memset(crow, 0, sizeof(int32_t) * (size_t)n);
+    for (int l = 0; l < k; ++l) {
+      const int32_t av = a[(int64_t)i * k + l];
+      const int8_t* brow = b + (int64_t)l * n;
+      for (int j = 0; j < n; ++j) crow[j] += av * (int32_t)brow[j];
+    }
+  }
+}
+
+/* lite/backends/arm/math/conv_impl.cc:490-598 (conv_im2col_gemm_int8) and :260-331
+ * (conv1x1s1_gemm_int8): serial over batch and groups, im2col into a workspace unless the conv is
+ * 1x1 s1 p0 (conv_gemmlike.cc:125), then one GEMM M = cout/g, K = cin/g*kh*kw, N = oh*ow. */
+void plref_conv2d_i8_acc_im2col_gemm(const plref_conv_shape* s, const int8_t* x, const int8_t* w,
+                                     int32_t* acc, int8_t* workspace) {
+  int oh, ow;
+  plref_conv_out_dims(s, &oh, &ow);
+  const int g = s->groups;
+  const int m = s->cout / g;
+  const int icg = s->cin / g;
+  const int k = icg * s->kh * s->kw;
+  const int n = oh * ow;
+  const int is_1x1 = s->kh == 1 && s->kw == 1 && s->stride[0] == 1 && s->stride[1] == 1 &&
+                     s->pad[0] == 0 && s->pad[1] == 0 && s->pad[2] == 0 && s->pad[3] == 0;
+  for (int b = 0; b < s->n; ++b) {
+    for (int grp = 0; grp < g; ++grp) {
+      const int8_t* xin = x + ((int64_t)b * s->cin + grp * icg) * s->h * s->w;
+      const int8_t* bmat = xin;
+      if (!is_1x1) {
+        plref_im2col_i8(xin, icg, s->h, s->w, s->kh, s->kw, s->pad, s->stride, s->dil, oh, ow,
+                        workspace);
+        bmat = workspace;
+      }
+      plref_gemm_i8_acc(m, n, k, w + (int64_t)grp * m * k, bmat,
+                        acc + ((int64_t)b * s->cout + grp * m) * n);
+    }
+  }
+}
+
+/* conv_gemmlike.cc:208-263, conv_depthwise.cc:146-158,242-271 — fp32 arithmetic, evaluated
+ * left-to-right exactly as written there (ws * in / out; bias / out; coef / out). */
+float plref_fold_scales(int int8_out, float in_scale, const float* w_scale, int n_wscale,
+                        float out_scale, const float* bias, int cout, int act, float alpha,
+                        float* scale_out, float* bias_out) {
+  for (int i = 0; i < cout; ++i) {
+    volatile float ws = w_scale[n_wscale == 1 ? 0 : i];
+    volatile float t = ws * in_scale;
+    if (int8_out) t = t / out_scale;
+    scale_out[i] = t;
+    float b = bias ? bias[i] : 0.f;
+    if (int8_out && bias) {
+      volatile float bb = b / out_scale;
+      b = bb;
+    }
+    bias_out[i] = b;
+  }
+  if (int8_out && act == PLREF_ACT_RELU6) {
+    volatile float a = alpha / out_scale;
+    return a;
+  }
+  return alpha;
+}
+
+/* saturate_cast<int8_t>(roundf(v)) then floor at -127: lite/backends/arm/math/saturate.h,
+ * conv_block_utils.h:3203-3225, type_trans.cc:183-184. */
+int8_t plref_round_sat_i8(float v) {
+  float r = roundf(v); /* ties away from zero (fcvtas) */
+  if (r > 127.f) r = 127.f;
+  if (r < -127.f) r = -127.f; /* sat to -128 then max(-127) == clamp at -127 */
+  if (r != r) r = 0.f;
+  return (int8_t)(int)r;
+}
+
+/* conv_block_utils.h:3188-3201; the multiply-add is a single fused fmla in the GEMM epilogue
+ * (gemm_prepacked_int8.cc:655-694), so one rounding. */
+float plref_epilogue_f32(int32_t acc, float scale, float bias, int act, float alpha) {
+  float y = fmaf((float)acc, scale, bias);
+  if (act == PLREF_ACT_RELU) {
+    y = y > 0.f ? y : 0.f;
+  } else if (act == PLREF_ACT_RELU6) {
+    y = y > 0.f ? y : 0.f;
+    y = y < alpha ? y : alpha;
+  } else if (act == PLREF_ACT_LEAKY) {
+    y = y > 0.f ? y : alpha * y;
+  }
+  return y;
+}
+
+int8_t plref_epilogue_i8(int32_t acc, float scale, float bias, int act, float alpha) {
+  return plref_round_sat_i8(plref_epilogue_f32(acc, scale, bias, act, alpha));
+}
+
+void plref_apply_epilogue_f32(const int32_t* acc, int n, int cout, int spatial, const float* scale,
+                              const float* bias, int act, float alpha, float* y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t nc = 0; nc < (int64_t)n * cout; ++nc) {
+    const int c = (int)(nc % cout);
+    for (int i = 0; i < spatial; ++i)
+      y[nc * spatial + i] = plref_epilogue_f32(acc[nc * spatial + i], scale[c], bias[c], act, alpha);
+  }
+}
+
+void plref_apply_epilogue_i8(const int32_t* acc, int n, int cout, int spatial, const float* scale,
+                             const float* bias, int act, float alpha, int8_t* y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t nc = 0; nc < (int64_t)n * cout; ++nc) {
+    const int c = (int)(nc % cout);
+    for (int i = 0; i < spatial; ++i)
+      y[nc * spatial + i] = plref_epilogue_i8(acc[nc * spatial + i], scale[c], bias[c], act, alpha);
+  }
+}
+
+/* fc_compute.cc:84-109 (m = prod(x.dims[:ncol]), k, n = w.dims[1]); w is [k, n]. */
+void plref_fc_i8_acc(int m, int n, int k, const int8_t* x, const int8_t* w, int32_t* acc) {
+  plref_gemm_i8_acc(m, n, k, x, w, acc);
+}
+
+void plref_fc_epilogue_f32(const int32_t* acc, int m, int n, const float* scale, const float* bias,
+                           int relu, float* y) {
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j)
+      y[(int64_t)i * n + j] = plref_epilogue_f32(acc[(int64_t)i * n + j], scale[j],
+                                                 bias ? bias[j] : 0.f, relu ? PLREF_ACT_RELU : 0, 0.f);
+}
+
+void plref_fc_epilogue_i8(const int32_t* acc, int m, int n, const float* scale, const float* bias,
+                          int relu, int8_t* y) {
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j)
+      y[(int64_t)i * n + j] = plref_epilogue_i8(acc[(int64_t)i * n + j], scale[j],
+                                                bias ? bias[j] : 0.f, relu ? PLREF_ACT_RELU : 0, 0.f);
+}
+
+/* type_trans.cc:45 (inv_scale = 1.f / scale), :183-184 (roundf(inv_scale * x), saturate, >= -127). */
+void plref_calib_f32_to_i8(const float* x, int8_t* y, float scale, int64_t count) {
+  volatile float inv = 1.f / scale;
+  const float inv_scale = inv;
+  for (int64_t i = 0; i < count; ++i) {
+    volatile float p = inv_scale * x[i];
+    y[i] = plref_round_sat_i8(p);
+  }
+}
+
+/* type_trans.cc:268-371: out = in_scale * in. */
+void plref_calib_i8_to_f32(const int8_t* x, float* y, float scale, int64_t count) {
+  for (int64_t i = 0; i < count; ++i) {
+    volatile float p = scale * (float)x[i];
+    y[i] = p;
+  }
+}
+
+/* pooling.cc:1006- (pooling_global_avg): sum over the plane, divide by its size. */
+void plref_global_avg_pool_f32(const float* x, int nc, int spatial, float* y) {
+  for (int i = 0; i < nc; ++i) {
+    double s = 0.0;
+    for (int j = 0; j < spatial; ++j) s += x[(int64_t)i * spatial + j];
+    y[i] = (float)(s / spatial);
+  }
+}
+
+/* softmax.cc (softmax_inner1): max-subtracted exp, normalised by the row sum. */
+void plref_softmax_f32(const float* x, int rows, int cols, float* y) {
+  for (int i = 0; i < rows; ++i) {
+    const float* xr = x + (int64_t)i * cols;
+    float* yr = y + (int64_t)i * cols;
+    float mx = xr[0];
+    for (int j = 1; j < cols; ++j) mx = xr[j] > mx ? xr[j] : mx;
+    double s = 0.0;
+    for (int j = 0; j < cols; ++j) {
+      yr[j] = expf(xr[j] - mx);
+      s += yr[j];
+    }
+    for (int j = 0; j < cols; ++j) yr[j] = (float)(yr[j] / s);
+  }
+}

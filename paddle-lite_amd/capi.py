@@ -1,0 +1,259 @@
+"""ctypes binding of libplhip.so (include/plhip.h) — the only way Python reaches the device code.
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails this raises.
+Used by tests/ (parity checks through the C ABI), bench.py and __graft_entry__.py.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplhip.so")
+
+OUT_I32, OUT_F32, OUT_I8 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 4
+_OUT_DTYPE = {OUT_I32: np.int32, OUT_F32: np.float32, OUT_I8: np.int8}
+
+# every symbol include/plhip.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "plhip_device_count", "plhip_ctx_create", "plhip_ctx_create_on_stream", "plhip_ctx_destroy",
+    "plhip_ctx_stream", "plhip_last_error", "plhip_malloc", "plhip_free", "plhip_memcpy_h2d",
+    "plhip_memcpy_d2h", "plhip_memcpy_d2d", "plhip_memset", "plhip_stream_sync", "plhip_event_create",
+    "plhip_event_record", "plhip_event_elapsed_ms", "plhip_event_destroy",
+    "plhip_conv_packed_weight_bytes", "plhip_pack_conv_weights", "plhip_conv_workspace_bytes",
+    "plhip_conv2d_int8", "plhip_conv_impl_name", "plhip_depthwise_conv_int8",
+    "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
+    "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
+    "plhip_selftest",
+]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("cin", C.c_int), ("h", C.c_int), ("w", C.c_int),
+                ("cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("pad", C.c_int * 4), ("stride", C.c_int * 2), ("dil", C.c_int * 2),
+                ("groups", C.c_int), ("act", C.c_int), ("act_alpha", C.c_float)]
+
+
+def conv_desc(n, cin, h, w, cout, kh, kw, pad=(0, 0, 0, 0), stride=(1, 1), dil=(1, 1), groups=1,
+              act=ACT_NONE, alpha=0.0):
+    d = ConvDesc()
+    d.n, d.cin, d.h, d.w, d.cout, d.kh, d.kw = n, cin, h, w, cout, kh, kw
+    if len(pad) == 2:
+        pad = (pad[0], pad[0], pad[1], pad[1])
+    d.pad[:] = [int(p) for p in pad]
+    d.stride[:] = [int(s) for s in stride]
+    d.dil[:] = [int(s) for s in dil]
+    d.groups, d.act, d.act_alpha = groups, act, alpha
+    return d
+
+
+def out_hw(d):
+    keh = d.dil[0] * (d.kh - 1) + 1
+    kew = d.dil[1] * (d.kw - 1) + 1
+    return ((d.h + d.pad[0] + d.pad[1] - keh) // d.stride[0] + 1,
+            (d.w + d.pad[2] + d.pad[3] - kew) // d.stride[1] + 1)
+
+
+class PlhipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libplhip.so and declare prototypes.  Raises if the library is absent (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PlhipError("%s is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.plhip_device_count.restype = i32
+    L.plhip_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.plhip_ctx_create_on_stream.argtypes = [i32, vp, C.POINTER(vp)]
+    L.plhip_ctx_destroy.argtypes = [vp]
+    L.plhip_ctx_destroy.restype = None
+    L.plhip_ctx_stream.argtypes = [vp]
+    L.plhip_ctx_stream.restype = vp
+    L.plhip_last_error.argtypes = [vp]
+    L.plhip_last_error.restype = C.c_char_p
+    L.plhip_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.plhip_free.argtypes = [vp, vp]
+    L.plhip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.plhip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.plhip_memcpy_d2d.argtypes = [vp, vp, vp, sz]
+    L.plhip_memset.argtypes = [vp, vp, i32, sz]
+    L.plhip_stream_sync.argtypes = [vp]
+    L.plhip_event_create.argtypes = [vp, C.POINTER(vp)]
+    L.plhip_event_record.argtypes = [vp, vp]
+    L.plhip_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(f32)]
+    L.plhip_event_destroy.argtypes = [vp, vp]
+    L.plhip_conv_packed_weight_bytes.argtypes = [C.POINTER(ConvDesc)]
+    L.plhip_conv_packed_weight_bytes.restype = sz
+    L.plhip_pack_conv_weights.argtypes = [vp, C.POINTER(ConvDesc), vp, vp]
+    L.plhip_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
+    L.plhip_conv_workspace_bytes.restype = sz
+    L.plhip_conv2d_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, sz]
+    L.plhip_conv_impl_name.argtypes = [C.POINTER(ConvDesc)]
+    L.plhip_conv_impl_name.restype = C.c_char_p
+    L.plhip_depthwise_conv_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32]
+    L.plhip_fc_packed_weight_bytes.argtypes = [i32, i32]
+    L.plhip_fc_packed_weight_bytes.restype = sz
+    L.plhip_pack_fc_weights.argtypes = [vp, i32, i32, vp, vp]
+    L.plhip_fc_int8.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32]
+    L.plhip_calib_f32_to_i8.argtypes = [vp, vp, vp, f32, C.c_int64]
+    L.plhip_calib_i8_to_f32.argtypes = [vp, vp, vp, f32, C.c_int64]
+    L.plhip_global_avg_pool_f32.argtypes = [vp, vp, i32, i32, vp]
+    L.plhip_softmax_f32.argtypes = [vp, vp, i32, i32, vp]
+    L.plhip_selftest.argtypes = [vp]
+    _lib = L
+    return L
+
+
+class Context:
+    """One plhip_ctx (device + stream).  Thin, explicit device-memory helpers for tests/bench."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load()
+        h = C.c_void_p()
+        if stream is None:
+            st = self.L.plhip_ctx_create(device, C.byref(h))
+        else:
+            st = self.L.plhip_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h))
+        if st != 0:
+            raise PlhipError("plhip_ctx_create failed (%d): %s" % (st, self.L.plhip_last_error(None).decode()))
+        self.h = h
+        self._allocs = []
+
+    def check(self, st, what=""):
+        if st != 0:
+            raise PlhipError("%s failed (%d): %s" % (what, st, self.L.plhip_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            for p in self._allocs:
+                self.L.plhip_free(self.h, p)
+            self._allocs = []
+            self.L.plhip_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- memory ----
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.L.plhip_malloc(self.h, nbytes, C.byref(p)), "plhip_malloc")
+        self._allocs.append(p)
+        return p
+
+    def free(self, p):
+        self._allocs = [q for q in self._allocs if q.value != p.value]
+        self.check(self.L.plhip_free(self.h, p), "plhip_free")
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(max(1, arr.nbytes))
+        if arr.nbytes:
+            self.check(self.L.plhip_memcpy_h2d(self.h, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes), "h2d")
+        return p
+
+    def to_host(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            self.check(self.L.plhip_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), p, out.nbytes), "d2h")
+        return out
+
+    def sync(self):
+        self.check(self.L.plhip_stream_sync(self.h), "sync")
+
+    def selftest(self):
+        self.check(self.L.plhip_selftest(self.h), "plhip_selftest")
+
+    # ---- whole-op helpers on host arrays (upload, run through the C ABI, download) ----
+    def conv2d(self, d, x, w, scale, bias, out_kind, depthwise=False):
+        oh, ow = out_hw(d)
+        dx = self.to_device(np.ascontiguousarray(x, np.int8))
+        dw = self.to_device(np.ascontiguousarray(w, np.int8))
+        ds = self.to_device(np.ascontiguousarray(scale, np.float32)) if scale is not None else C.c_void_p()
+        db = self.to_device(np.ascontiguousarray(bias, np.float32)) if bias is not None else C.c_void_p()
+        esz = 1 if out_kind == OUT_I8 else 4
+        dy = self.malloc(d.n * d.cout * oh * ow * esz)
+        tmp = [dx, dw, dy]
+        if depthwise:
+            self.check(self.L.plhip_depthwise_conv_int8(self.h, C.byref(d), dx, dw, ds, db, dy, out_kind), "depthwise")
+        else:
+            dwp = self.malloc(self.L.plhip_conv_packed_weight_bytes(C.byref(d)))
+            self.check(self.L.plhip_pack_conv_weights(self.h, C.byref(d), dw, dwp), "pack")
+            wsb = self.L.plhip_conv_workspace_bytes(C.byref(d))
+            dws = self.malloc(wsb) if wsb else C.c_void_p()
+            self.check(self.L.plhip_conv2d_int8(self.h, C.byref(d), dx, dwp, ds, db, dy, out_kind, dws, wsb), "conv2d")
+            tmp += [dwp] + ([dws] if wsb else [])
+        y = self.to_host(dy, (d.n, d.cout, oh, ow), _OUT_DTYPE[out_kind])
+        for p in tmp + ([ds] if scale is not None else []) + ([db] if bias is not None else []):
+            self.free(p)
+        return y
+
+    def fc(self, x, w, scale, bias, relu, out_kind):
+        x = np.ascontiguousarray(x, np.int8)
+        w = np.ascontiguousarray(w, np.int8)
+        m, k = x.shape
+        n = w.shape[1]
+        dx, dw = self.to_device(x), self.to_device(w)
+        dwp = self.malloc(self.L.plhip_fc_packed_weight_bytes(k, n))
+        self.check(self.L.plhip_pack_fc_weights(self.h, k, n, dw, dwp), "pack_fc")
+        ds = self.to_device(np.ascontiguousarray(scale, np.float32)) if scale is not None else C.c_void_p()
+        db = self.to_device(np.ascontiguousarray(bias, np.float32)) if bias is not None else C.c_void_p()
+        esz = 1 if out_kind == OUT_I8 else 4
+        dy = self.malloc(m * n * esz)
+        self.check(self.L.plhip_fc_int8(self.h, m, k, n, dx, dwp, ds, db, int(relu), dy, out_kind), "fc")
+        y = self.to_host(dy, (m, n), _OUT_DTYPE[out_kind])
+        for p in [dx, dw, dwp, dy] + ([ds] if scale is not None else []) + ([db] if bias is not None else []):
+            self.free(p)
+        return y
+
+    def calib_f32_to_i8(self, x, scale):
+        x = np.ascontiguousarray(x, np.float32)
+        dx = self.to_device(x)
+        dy = self.malloc(max(1, x.size))
+        self.check(self.L.plhip_calib_f32_to_i8(self.h, dx, dy, scale, x.size), "calib_f32_to_i8")
+        y = self.to_host(dy, x.shape, np.int8)
+        self.free(dx), self.free(dy)
+        return y
+
+    def calib_i8_to_f32(self, x, scale):
+        x = np.ascontiguousarray(x, np.int8)
+        dx = self.to_device(x)
+        dy = self.malloc(max(4, x.size * 4))
+        self.check(self.L.plhip_calib_i8_to_f32(self.h, dx, dy, scale, x.size), "calib_i8_to_f32")
+        y = self.to_host(dy, x.shape, np.float32)
+        self.free(dx), self.free(dy)
+        return y
+
+    def global_avg_pool(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        n, c = x.shape[:2]
+        sp = int(np.prod(x.shape[2:]))
+        dx = self.to_device(x)
+        dy = self.malloc(n * c * 4)
+        self.check(self.L.plhip_global_avg_pool_f32(self.h, dx, n * c, sp, dy), "pool")
+        y = self.to_host(dy, (n, c, 1, 1), np.float32)
+        self.free(dx), self.free(dy)
+        return y
+
+    def softmax(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        rows, cols = int(np.prod(x.shape[:-1])), x.shape[-1]
+        dx = self.to_device(x)
+        dy = self.malloc(x.size * 4)
+        self.check(self.L.plhip_softmax_f32(self.h, dx, rows, cols, dy), "softmax")
+        y = self.to_host(dy, x.shape, np.float32)
+        self.free(dx), self.free(dy)
+        return y

@@ -1,0 +1,187 @@
+// misc_ops.hip — fc (int8), calib (fp32<->int8), global average pool and softmax (fp32) for gfx950.
+//
+// Replaces (reference, ARM):
+//   fc      FcCompute<kInt8,*>::Run   lite/kernels/arm/fc_compute.cc:229-344 -> gemm_s8 / gemv_int8
+//   calib   CalibCompute*             lite/kernels/arm/calib_compute.cc:25-57 -> type_trans.cc:34-187, 268-371
+//   pool    pooling_global_avg        lite/backends/arm/math/pooling.cc:1006-
+//   softmax softmax_inner1            lite/backends/arm/math/softmax.cc
+// All four are tiny in the MobileNet graph (FC = 1 MMAC / image); they are kept on device so that the
+// whole graph runs without host round trips.  FC uses v_dot4_i32_i8 on a [k/4][n][4] pre-packed weight:
+// lanes walk n (coalesced dword per k-quad), the x dwords are wave-uniform.
+#include "plhip_device.h"
+#include "plhip_kernels.h"
+
+namespace plhip {
+
+// w [k][n] -> wp [(k+3)/4][n][4]  (zero padded in k)
+__global__ void pack_fc_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp, int k, int n) {
+  const int k4n = (k + 3) / 4;
+  const size_t total = (size_t)k4n * n * 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = idx & 3;
+    const size_t t = idx >> 2;
+    const int col = (int)(t % n);
+    const int kq = (int)(t / n);
+    const int kk = kq * 4 + j;
+    wp[idx] = kk < k ? w[(size_t)kk * n + col] : (int8_t)0;
+  }
+}
+
+// One thread: one output column n for FC_MB consecutive rows m.  x rows must be readable as dwords:
+// the tail quad of a row (k % 4 != 0) is assembled bytewise.
+#define FC_MB 8
+template <int OUT>
+__global__ __launch_bounds__(256) void fc_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ wp,
+                                                    const float* __restrict__ scale, const float* __restrict__ bias,
+                                                    void* __restrict__ y, int m, int k, int n, int relu) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * FC_MB;
+  const int k4n = (k + 3) / 4;
+  int acc[FC_MB];
+#pragma unroll
+  for (int i = 0; i < FC_MB; ++i) acc[i] = 0;
+  const int colc = col < n ? col : n - 1;
+  const uint32_t* wq = reinterpret_cast<const uint32_t*>(wp) + colc;
+  for (int kq = 0; kq < k4n; ++kq) {
+    const int wv = (int)wq[(size_t)kq * n];
+#pragma unroll
+    for (int i = 0; i < FC_MB; ++i) {
+      const int mi = m0 + i < m ? m0 + i : m - 1;
+      const int8_t* xr = x + (size_t)mi * k + kq * 4;
+      uint32_t xv = 0;
+      if (kq * 4 + 3 < k) {
+        __builtin_memcpy(&xv, xr, 4);
+      } else {
+        for (int j = 0; j < 4; ++j)
+          if (kq * 4 + j < k) xv |= (uint32_t)(uint8_t)xr[j] << (8 * j);
+      }
+      acc[i] = __builtin_amdgcn_sdot4((int)xv, wv, acc[i], false);
+    }
+  }
+  if (col >= n) return;
+  const float s = (OUT == OUT_I32) ? 1.f : scale[col];
+  const float bi = (OUT != OUT_I32 && bias) ? bias[col] : 0.f;
+#pragma unroll
+  for (int i = 0; i < FC_MB; ++i) {
+    if (m0 + i >= m) break;
+    const size_t off = (size_t)(m0 + i) * n + col;
+    if (OUT == OUT_I32) {
+      reinterpret_cast<int*>(y)[off] = acc[i];
+    } else {
+      // fp32-out spec: fma(float(acc), s, b) then relu
+      const float f = epilogue_f32(acc[i], s, bi, relu ? ACT_RELU : ACT_NONE, 0.f);
+      if (OUT == OUT_F32) reinterpret_cast<float*>(y)[off] = f;
+      else reinterpret_cast<int8_t*>(y)[off] = (int8_t)round_sat_i8(f);
+    }
+  }
+}
+
+// q = clamp(round_half_away(x * (1.f/scale)), -127, 127)   type_trans.cc:45,183-184
+__global__ void calib_f32_to_i8_kernel(const float* __restrict__ x, int8_t* __restrict__ y, float inv_scale, int64_t count, int vec) {
+  const int64_t nq = vec ? count >> 2 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
+    const v4f v = reinterpret_cast<const v4f*>(x)[i];
+    reinterpret_cast<uint32_t*>(y)[i] = pack4_i8(round_sat_i8(inv_scale * v[0]), round_sat_i8(inv_scale * v[1]),
+                                                 round_sat_i8(inv_scale * v[2]), round_sat_i8(inv_scale * v[3]));
+  }
+  for (int64_t t = (nq << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride)
+    y[t] = (int8_t)round_sat_i8(inv_scale * x[t]);
+}
+
+// x = q * scale   type_trans.cc:268-371
+__global__ void calib_i8_to_f32_kernel(const int8_t* __restrict__ x, float* __restrict__ y, float scale, int64_t count, int vec) {
+  const int64_t nq = vec ? count >> 2 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
+    const uint32_t v = reinterpret_cast<const uint32_t*>(x)[i];
+    v4f o;
+    o[0] = scale * (float)(int8_t)(v & 0xff);
+    o[1] = scale * (float)(int8_t)((v >> 8) & 0xff);
+    o[2] = scale * (float)(int8_t)((v >> 16) & 0xff);
+    o[3] = scale * (float)(int8_t)(v >> 24);
+    reinterpret_cast<v4f*>(y)[i] = o;
+  }
+  for (int64_t t = (nq << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride)
+    y[t] = scale * (float)x[t];
+}
+
+// one wave per (n, c) plane
+__global__ __launch_bounds__(256) void global_avg_pool_kernel(const float* __restrict__ x, int nc, int spatial, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (plane >= nc) return;
+  const float* p = x + (size_t)plane * spatial;
+  float s = 0.f;
+  for (int i = lane; i < spatial; i += 64) s += p[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) y[plane] = s / (float)spatial;
+}
+
+// one block per row
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ x, int cols, float* __restrict__ y) {
+  __shared__ float red[4];
+  const float* xr = x + (size_t)blockIdx.x * cols;
+  float* yr = y + (size_t)blockIdx.x * cols;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = -3.402823466e38f;
+  for (int i = threadIdx.x; i < cols; i += 256) mx = fmaxf(mx, xr[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) s += expf(xr[i] - mx);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int i = threadIdx.x; i < cols; i += 256) yr[i] = expf(xr[i] - mx) / s;
+}
+
+void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s) {
+  const size_t total = (size_t)((k + 3) / 4) * n * 4;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_fc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w_kn, wp, k, n);
+}
+
+void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const float* bias, void* y, int m, int k, int n,
+               int relu, int out, hipStream_t s) {
+  dim3 grid((n + 255) / 256, (m + FC_MB - 1) / FC_MB);
+  if (out == OUT_I32) hipLaunchKernelGGL((fc_i8_kernel<OUT_I32>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
+  else if (out == OUT_F32) hipLaunchKernelGGL((fc_i8_kernel<OUT_F32>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
+  else hipLaunchKernelGGL((fc_i8_kernel<OUT_I8>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
+}
+
+static unsigned ew_blocks(int64_t quads) {
+  int64_t b = (quads + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048 * 4) b = 2048 * 4;
+  return (unsigned)b;
+}
+
+void launch_calib_f32_to_i8(const float* x, int8_t* y, float scale, int64_t count, hipStream_t s) {
+  const float inv = 1.f / scale;  // type_trans.cc:45
+  const int vec = (((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 3) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(calib_f32_to_i8_kernel, dim3(ew_blocks(vec ? count >> 2 : count)), dim3(256), 0, s, x, y, inv, count, vec);
+}
+
+void launch_calib_i8_to_f32(const int8_t* x, float* y, float scale, int64_t count, hipStream_t s) {
+  const int vec = (((uintptr_t)y & 15) == 0 && ((uintptr_t)x & 3) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(calib_i8_to_f32_kernel, dim3(ew_blocks(vec ? count >> 2 : count)), dim3(256), 0, s, x, y, scale, count, vec);
+}
+
+void launch_global_avg_pool(const float* x, int nc, int spatial, float* y, hipStream_t s) {
+  hipLaunchKernelGGL(global_avg_pool_kernel, dim3((nc + 3) / 4), dim3(256), 0, s, x, nc, spatial, y);
+}
+
+void launch_softmax(const float* x, int rows, int cols, float* y, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(256), 0, s, x, cols, y);
+}
+
+}  // namespace plhip

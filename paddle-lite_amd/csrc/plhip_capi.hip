@@ -1,0 +1,477 @@
+// plhip_capi.hip — the C ABI (include/plhip.h) over the gfx950 kernels: argument validation, path
+// selection (the analogue of ConvCompute<kInt8,*>::PrepareForRun's impl_ choice,
+// lite/kernels/arm/conv_compute.cc:87-185) and launches.  No allocation and no synchronisation happens
+// inside a compute entry point, so callers may capture them into a hipGraph.
+#include "../../include/plhip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "plhip_kernels.h"
+
+struct plhip_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  char err[512];
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+plhip_status fail(plhip_ctx* c, plhip_status st, const char* fmt, const char* a = "", const char* b = "") {
+  char* dst = c ? c->err : g_err;
+  snprintf(dst, 512, fmt, a, b);
+  return st;
+}
+
+#define HIPCHK(ctx, call)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) return fail((ctx), PLHIP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define LAUNCHCHK(ctx, what)                                                                      \
+  do {                                                                                            \
+    hipError_t e_ = hipGetLastError();                                                            \
+    if (e_ != hipSuccess) return fail((ctx), PLHIP_ERR_HIP, "launch %s failed: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int rup(int a, int b) { return cdiv(a, b) * b; }
+
+struct ConvGeom {
+  int oh, ow, G, Mg, Cg, Kg, N, Np, MA, MT, MT32, KS;
+  bool is_1x1_s1_p0;
+};
+
+bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
+  if (!d || d->n < 1 || d->cin < 1 || d->cout < 1 || d->h < 1 || d->w < 1 || d->kh < 1 || d->kw < 1) return false;
+  if (d->groups < 1 || d->cin % d->groups || d->cout % d->groups) return false;
+  if (d->stride[0] < 1 || d->stride[1] < 1 || d->dil[0] < 1 || d->dil[1] < 1) return false;
+  for (int i = 0; i < 4; ++i)
+    if (d->pad[i] < 0) return false;
+  // conv_int8_compute_test.cc:67-88
+  const int keh = d->dil[0] * (d->kh - 1) + 1, kew = d->dil[1] * (d->kw - 1) + 1;
+  const int hn = d->h + d->pad[0] + d->pad[1] - keh, wn = d->w + d->pad[2] + d->pad[3] - kew;
+  if (hn < 0 || wn < 0) return false;
+  g->oh = hn / d->stride[0] + 1;
+  g->ow = wn / d->stride[1] + 1;
+  g->G = d->groups;
+  g->Mg = d->cout / d->groups;
+  g->Cg = d->cin / d->groups;
+  g->Kg = g->Cg * d->kh * d->kw;
+  g->N = g->oh * g->ow;
+  g->Np = rup(g->N, 4);
+  g->MA = g->Mg > 32 ? 2 : 1;
+  g->MT = cdiv(g->Mg, 32 * g->MA);
+  g->MT32 = g->MT * g->MA;
+  g->KS = cdiv(g->Kg, 32);
+  g->is_1x1_s1_p0 = d->kh == 1 && d->kw == 1 && d->stride[0] == 1 && d->stride[1] == 1 && d->pad[0] == 0 &&
+                    d->pad[1] == 0 && d->pad[2] == 0 && d->pad[3] == 0;
+  return true;
+}
+
+inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int plhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static plhip_status ctx_new(int device_id, hipStream_t stream, bool own, plhip_ctx** out) {
+  if (!out) return fail(nullptr, PLHIP_ERR_INVALID, "null out pointer");
+  int n = plhip_device_count();
+  if (device_id < 0 || device_id >= n) return fail(nullptr, PLHIP_ERR_NO_DEVICE, "no HIP device %s", "with that id");
+  HIPCHK(nullptr, hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCHK(nullptr, hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, PLHIP_ERR_NO_DEVICE, "device arch %s is not gfx950 (this library carries gfx950 code objects only)",
+                prop.gcnArchName);
+  plhip_ctx* c = new plhip_ctx;
+  c->device = device_id;
+  c->own_stream = own;
+  c->err[0] = 0;
+  if (own) {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return fail(nullptr, PLHIP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+  } else {
+    c->stream = stream;
+  }
+  *out = c;
+  return PLHIP_OK;
+}
+
+plhip_status plhip_ctx_create(int device_id, plhip_ctx** out) { return ctx_new(device_id, nullptr, true, out); }
+
+plhip_status plhip_ctx_create_on_stream(int device_id, void* hip_stream, plhip_ctx** out) {
+  return ctx_new(device_id, (hipStream_t)hip_stream, false, out);
+}
+
+void plhip_ctx_destroy(plhip_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+void* plhip_ctx_stream(plhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+const char* plhip_last_error(plhip_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+plhip_status plhip_malloc(plhip_ctx* ctx, size_t bytes, void** dev_ptr) {
+  if (!ctx || !dev_ptr) return fail(ctx, PLHIP_ERR_INVALID, "plhip_malloc: null argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc(dev_ptr, bytes ? bytes : 1));
+  return PLHIP_OK;
+}
+plhip_status plhip_free(plhip_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return fail(ctx, PLHIP_ERR_INVALID, "plhip_free: null ctx");
+  if (dev_ptr) HIPCHK(ctx, hipFree(dev_ptr));
+  return PLHIP_OK;
+}
+plhip_status plhip_memcpy_h2d(plhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return fail(ctx, PLHIP_ERR_INVALID, "null ctx");
+  if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // pageable host memory: complete before returning
+  return PLHIP_OK;
+}
+plhip_status plhip_memcpy_d2h(plhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return fail(ctx, PLHIP_ERR_INVALID, "null ctx");
+  if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PLHIP_OK;
+}
+plhip_status plhip_memcpy_d2d(plhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return fail(ctx, PLHIP_ERR_INVALID, "null ctx");
+  if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return PLHIP_OK;
+}
+plhip_status plhip_memset(plhip_ctx* ctx, void* dst, int value, size_t bytes) {
+  if (!ctx) return fail(ctx, PLHIP_ERR_INVALID, "null ctx");
+  if (bytes) HIPCHK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+  return PLHIP_OK;
+}
+plhip_status plhip_stream_sync(plhip_ctx* ctx) {
+  if (!ctx) return fail(ctx, PLHIP_ERR_INVALID, "null ctx");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PLHIP_OK;
+}
+plhip_status plhip_event_create(plhip_ctx* ctx, void** event) {
+  if (!ctx || !event) return fail(ctx, PLHIP_ERR_INVALID, "null argument");
+  hipEvent_t e;
+  HIPCHK(ctx, hipEventCreate(&e));
+  *event = (void*)e;
+  return PLHIP_OK;
+}
+plhip_status plhip_event_record(plhip_ctx* ctx, void* event) {
+  if (!ctx || !event) return fail(ctx, PLHIP_ERR_INVALID, "null argument");
+  HIPCHK(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+  return PLHIP_OK;
+}
+plhip_status plhip_event_elapsed_ms(plhip_ctx* ctx, void* start, void* stop, float* ms) {
+  if (!ctx || !start || !stop || !ms) return fail(ctx, PLHIP_ERR_INVALID, "null argument");
+  HIPCHK(ctx, hipEventSynchronize((hipEvent_t)stop));
+  HIPCHK(ctx, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return PLHIP_OK;
+}
+plhip_status plhip_event_destroy(plhip_ctx* ctx, void* event) {
+  if (event) HIPCHK(ctx, hipEventDestroy((hipEvent_t)event));
+  return PLHIP_OK;
+}
+
+// ------------------------------------------------------------------ conv2d
+size_t plhip_conv_packed_weight_bytes(const plhip_conv_desc* d) {
+  ConvGeom g;
+  if (!conv_geom(d, &g)) return 0;
+  return (size_t)g.G * g.MT32 * g.KS * 1024;
+}
+
+plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* w_oihw, void* w_packed) {
+  ConvGeom g;
+  if (!ctx || !w_oihw || !w_packed) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pack_conv_weights: null argument");
+  if (!conv_geom(d, &g)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pack_conv_weights: bad conv descriptor");
+  plhip::launch_pack_weights(w_oihw, (int8_t*)w_packed, g.G, g.Mg, g.Kg, g.MT32, g.KS, ctx->stream);
+  LAUNCHCHK(ctx, "pack_weights");
+  return PLHIP_OK;
+}
+
+size_t plhip_conv_workspace_bytes(const plhip_conv_desc* d) {
+  ConvGeom g;
+  if (!conv_geom(d, &g)) return 0;
+  if (g.is_1x1_s1_p0 && (g.N & 3) == 0) return 0;
+  return (size_t)d->n * g.G * g.Kg * g.Np;
+}
+
+const char* plhip_conv_impl_name(const plhip_conv_desc* d) {
+  ConvGeom g;
+  if (!conv_geom(d, &g)) return "invalid";
+  if (g.is_1x1_s1_p0 && (g.N & 3) == 0) return "conv1x1s1_gemm_int8_mfma32x32x32";
+  return "conv_im2col_gemm_int8_mfma32x32x32";
+}
+
+plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x, const void* w_packed,
+                               const float* scale, const float* bias, void* y, plhip_out_kind out, void* workspace,
+                               size_t workspace_bytes) {
+  ConvGeom g;
+  if (!ctx || !x || !w_packed || !y) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: null argument");
+  if (!conv_geom(d, &g)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: bad conv descriptor");
+  if (out != PLHIP_OUT_I32_ACC && out != PLHIP_OUT_F32 && out != PLHIP_OUT_I8)
+    return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: bad out kind");
+  if (out != PLHIP_OUT_I32_ACC && !scale) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: scale required");
+  if (d->act != PLHIP_ACT_NONE && d->act != PLHIP_ACT_RELU && d->act != PLHIP_ACT_RELU6 && d->act != PLHIP_ACT_LEAKY_RELU)
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_int8: unsupported activation");
+  if ((size_t)d->n * g.Np >= ((size_t)1 << 31) - 256 || (size_t)d->cin * d->h * d->w >= ((size_t)1 << 31))
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_int8: tensor too large for 32-bit column index");
+
+  const bool direct = g.is_1x1_s1_p0 && (g.N & 3) == 0 && aligned(x, 4);
+  const int8_t* bmat = x;
+  size_t x_bstride = (size_t)d->cin * g.N, x_gstride = (size_t)g.Cg * g.N;
+  int hwx = g.N;
+  if (!direct) {
+    const size_t need = (size_t)d->n * g.G * g.Kg * g.Np;
+    if (!workspace || workspace_bytes < need || !aligned(workspace, 4))
+      return fail(ctx, PLHIP_ERR_WORKSPACE, "plhip_conv2d_int8: im2col workspace missing, too small or unaligned");
+    plhip::Im2colArgs ia;
+    ia.x = x;
+    ia.col = (int8_t*)workspace;
+    ia.cin = d->cin;
+    ia.cin_g = g.Cg;
+    ia.h = d->h;
+    ia.w = d->w;
+    ia.kh = d->kh;
+    ia.kw = d->kw;
+    ia.pt = d->pad[0];
+    ia.pl = d->pad[2];
+    ia.sh = d->stride[0];
+    ia.sw = d->stride[1];
+    ia.dh = d->dil[0];
+    ia.dw = d->dil[1];
+    ia.oh = g.oh;
+    ia.ow = g.ow;
+    ia.G = g.G;
+    ia.Kg = g.Kg;
+    ia.N = g.N;
+    ia.Np = g.Np;
+    ia.rows = (size_t)d->n * g.G * g.Kg;
+    plhip::launch_im2col(ia, ctx->stream);
+    LAUNCHCHK(ctx, "im2col");
+    bmat = (const int8_t*)workspace;
+    x_bstride = (size_t)g.G * g.Kg * g.Np;
+    x_gstride = (size_t)g.Kg * g.Np;
+    hwx = g.Np;
+  }
+  const size_t esz = out == PLHIP_OUT_I8 ? 1 : 4;
+  const bool vec_store = hwx == g.N && aligned(y, 4 * esz);
+  for (int grp = 0; grp < g.G; ++grp) {
+    plhip::GemmArgs a;
+    a.wp = (const int8_t*)w_packed + (size_t)grp * g.MT32 * g.KS * 1024;
+    a.x = bmat + (size_t)grp * x_gstride;
+    a.y = (char*)y + (size_t)grp * g.Mg * g.N * esz;
+    a.scale = scale ? scale + (size_t)grp * g.Mg : nullptr;
+    a.bias = bias ? bias + (size_t)grp * g.Mg : nullptr;
+    a.M = g.Mg;
+    a.K = g.Kg;
+    a.KS = g.KS;
+    a.HWX = hwx;
+    a.HWY = g.N;
+    a.NB = d->n;
+    a.x_bstride = x_bstride;
+    a.y_bstride = (size_t)d->cout * g.N;
+    a.MT = g.MT;
+    a.NT = cdiv(d->n * hwx, 128);
+    a.act = d->act;
+    a.alpha = d->act_alpha;
+    plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store, ctx->stream);
+    LAUNCHCHK(ctx, "gemm_i8");
+  }
+  return PLHIP_OK;
+}
+
+// ------------------------------------------------------------------ depthwise
+plhip_status plhip_depthwise_conv_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x, const int8_t* w_oihw,
+                                       const float* scale, const float* bias, void* y, plhip_out_kind out) {
+  ConvGeom g;
+  if (!ctx || !x || !w_oihw || !y) return fail(ctx, PLHIP_ERR_INVALID, "plhip_depthwise_conv_int8: null argument");
+  if (!conv_geom(d, &g)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_depthwise_conv_int8: bad conv descriptor");
+  if (d->groups != d->cin || d->cin != d->cout)
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_depthwise_conv_int8: needs groups == cin == cout");
+  if (out != PLHIP_OUT_I32_ACC && !scale) return fail(ctx, PLHIP_ERR_INVALID, "plhip_depthwise_conv_int8: scale required");
+  if (d->act != PLHIP_ACT_NONE && d->act != PLHIP_ACT_RELU && d->act != PLHIP_ACT_RELU6 && d->act != PLHIP_ACT_LEAKY_RELU)
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_depthwise_conv_int8: unsupported activation");
+  const size_t esz = out == PLHIP_OUT_I8 ? 1 : 4;
+  if (!aligned(y, 4 * esz) && (g.ow & 3) == 0)
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_depthwise_conv_int8: output pointer must be 4-element aligned");
+
+  plhip::DwArgs a;
+  a.x = x;
+  a.wt = w_oihw;
+  a.y = y;
+  a.scale = scale;
+  a.bias = bias;
+  a.planes = d->n * d->cin;
+  a.C = d->cin;
+  a.h = d->h;
+  a.w = d->w;
+  a.oh = g.oh;
+  a.ow = g.ow;
+  a.kh = d->kh;
+  a.kw = d->kw;
+  a.pt = d->pad[0];
+  a.pl = d->pad[2];
+  a.sh = d->stride[0];
+  a.sw = d->stride[1];
+  a.dh = d->dil[0];
+  a.dw = d->dil[1];
+  a.act = d->act;
+  a.alpha = d->act_alpha;
+  // Tiling: a block covers PB planes x OB output rows; aim at ~2K quads (8 per thread) per block and keep
+  // the LDS tile under 48 KiB so that several blocks share a CU.
+  const int owq = cdiv(g.ow, 4);
+  const int OFF = rup(d->pad[2], 4);
+  const int maxcol = (4 * owq - 1) * d->stride[1] - d->pad[2] + (d->kw - 1) * d->dil[1] + OFF;
+  int pitch = rup((maxcol > OFF + d->w ? maxcol : OFF + d->w) + 1 + 16, 4);
+  const int target = 2048;
+  int OB, PB;
+  if (g.oh * owq >= target) {
+    PB = 1;
+    OB = target / owq;
+    if (OB < 1) OB = 1;
+    if (OB > g.oh) OB = g.oh;
+  } else {
+    OB = g.oh;
+    PB = target / (g.oh * owq);
+    if (PB < 1) PB = 1;
+    if (PB > 64) PB = 64;
+    if (PB > a.planes) PB = a.planes;
+  }
+  auto in_rows_of = [&](int ob) { return (ob - 1) * d->stride[0] + (d->kh - 1) * d->dil[0] + 1; };
+  auto lds_of = [&](int pb, int ob) {
+    return (size_t)pb * in_rows_of(ob) * pitch + (size_t)pb * d->kh * 8 + (size_t)pb * 8 + (size_t)pb * d->kh * d->kw + 16;
+  };
+  while (lds_of(PB, OB) > 48 * 1024 && PB > 1) PB = PB / 2;
+  while (lds_of(PB, OB) > 48 * 1024 && OB > 1) OB = (OB + 1) / 2;
+  if (lds_of(PB, OB) > 60 * 1024)
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_depthwise_conv_int8: a single row band does not fit in LDS");
+  a.PB = PB;
+  a.OB = OB;
+  a.bands = cdiv(g.oh, OB);
+  a.in_rows = in_rows_of(OB);
+  a.pitch = pitch;
+  if (plhip::launch_depthwise(a, (int)out, ctx->stream) != 0)
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_depthwise_conv_int8: LDS tile too large");
+  LAUNCHCHK(ctx, "depthwise_i8");
+  return PLHIP_OK;
+}
+
+// ------------------------------------------------------------------ fc
+size_t plhip_fc_packed_weight_bytes(int k, int n) {
+  if (k < 1 || n < 1) return 0;
+  return (size_t)((k + 3) / 4) * n * 4;
+}
+
+plhip_status plhip_pack_fc_weights(plhip_ctx* ctx, int k, int n, const int8_t* w_kn, void* w_packed) {
+  if (!ctx || !w_kn || !w_packed || k < 1 || n < 1) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pack_fc_weights: bad argument");
+  plhip::launch_pack_fc(w_kn, (int8_t*)w_packed, k, n, ctx->stream);
+  LAUNCHCHK(ctx, "pack_fc");
+  return PLHIP_OK;
+}
+
+plhip_status plhip_fc_int8(plhip_ctx* ctx, int m, int k, int n, const int8_t* x, const void* w_packed, const float* scale,
+                           const float* bias, int relu, void* y, plhip_out_kind out) {
+  if (!ctx || !x || !w_packed || !y || m < 1 || k < 1 || n < 1) return fail(ctx, PLHIP_ERR_INVALID, "plhip_fc_int8: bad argument");
+  if (out != PLHIP_OUT_I32_ACC && out != PLHIP_OUT_F32 && out != PLHIP_OUT_I8)
+    return fail(ctx, PLHIP_ERR_INVALID, "plhip_fc_int8: bad out kind");
+  if (out != PLHIP_OUT_I32_ACC && !scale) return fail(ctx, PLHIP_ERR_INVALID, "plhip_fc_int8: scale required");
+  if (!aligned(w_packed, 4)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_fc_int8: packed weights must be 4-byte aligned");
+  plhip::launch_fc(x, (const int8_t*)w_packed, scale, bias, y, m, k, n, relu, (int)out, ctx->stream);
+  LAUNCHCHK(ctx, "fc_i8");
+  return PLHIP_OK;
+}
+
+// ------------------------------------------------------------------ calib / pool / softmax
+plhip_status plhip_calib_f32_to_i8(plhip_ctx* ctx, const float* x, int8_t* y, float scale, int64_t count) {
+  if (!ctx || !x || !y || count < 0 || !(scale > 0.f)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_calib_f32_to_i8: bad argument");
+  if (count == 0) return PLHIP_OK;
+  plhip::launch_calib_f32_to_i8(x, y, scale, count, ctx->stream);
+  LAUNCHCHK(ctx, "calib_f32_to_i8");
+  return PLHIP_OK;
+}
+
+plhip_status plhip_calib_i8_to_f32(plhip_ctx* ctx, const int8_t* x, float* y, float scale, int64_t count) {
+  if (!ctx || !x || !y || count < 0) return fail(ctx, PLHIP_ERR_INVALID, "plhip_calib_i8_to_f32: bad argument");
+  if (count == 0) return PLHIP_OK;
+  plhip::launch_calib_i8_to_f32(x, y, scale, count, ctx->stream);
+  LAUNCHCHK(ctx, "calib_i8_to_f32");
+  return PLHIP_OK;
+}
+
+plhip_status plhip_global_avg_pool_f32(plhip_ctx* ctx, const float* x, int nc, int spatial, float* y) {
+  if (!ctx || !x || !y || nc < 1 || spatial < 1) return fail(ctx, PLHIP_ERR_INVALID, "plhip_global_avg_pool_f32: bad argument");
+  plhip::launch_global_avg_pool(x, nc, spatial, y, ctx->stream);
+  LAUNCHCHK(ctx, "global_avg_pool");
+  return PLHIP_OK;
+}
+
+plhip_status plhip_softmax_f32(plhip_ctx* ctx, const float* x, int rows, int cols, float* y) {
+  if (!ctx || !x || !y || rows < 1 || cols < 1) return fail(ctx, PLHIP_ERR_INVALID, "plhip_softmax_f32: bad argument");
+  plhip::launch_softmax(x, rows, cols, y, ctx->stream);
+  LAUNCHCHK(ctx, "softmax");
+  return PLHIP_OK;
+}
+
+// ------------------------------------------------------------------ self test
+// Known-answer 1x1 conv (M = 70, K = 45, N = 2 x 36) with asymmetric data, int32 accumulators compared with a host
+// triple loop: proves the MFMA operand / accumulator lane maps and the in-register transpose on this device.
+plhip_status plhip_selftest(plhip_ctx* ctx) {
+  if (!ctx) return fail(ctx, PLHIP_ERR_INVALID, "null ctx");
+  plhip_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.n = 2; d.cin = 45; d.h = 6; d.w = 6; d.cout = 70; d.kh = 1; d.kw = 1;
+  d.stride[0] = d.stride[1] = 1; d.dil[0] = d.dil[1] = 1; d.groups = 1;
+  const int N = 36;
+  std::vector<int8_t> hx((size_t)d.n * d.cin * N), hw((size_t)d.cout * d.cin);
+  for (size_t i = 0; i < hx.size(); ++i) hx[i] = (int8_t)((int)((i * 37 + (i >> 3) * 11 + 5) % 255) - 127);
+  for (size_t i = 0; i < hw.size(); ++i) hw[i] = (int8_t)((int)((i * 101 + (i >> 2) * 7 + 13) % 255) - 127);
+  std::vector<int32_t> ref((size_t)d.n * d.cout * N), got(ref.size());
+  for (int b = 0; b < d.n; ++b)
+    for (int m = 0; m < d.cout; ++m)
+      for (int n = 0; n < N; ++n) {
+        int32_t s = 0;
+        for (int k = 0; k < d.cin; ++k) s += (int32_t)hw[(size_t)m * d.cin + k] * (int32_t)hx[((size_t)b * d.cin + k) * N + n];
+        ref[((size_t)b * d.cout + m) * N + n] = s;
+      }
+  void *dx = nullptr, *dw = nullptr, *dwp = nullptr, *dy = nullptr;
+  plhip_status st;
+  if ((st = plhip_malloc(ctx, hx.size(), &dx)) || (st = plhip_malloc(ctx, hw.size(), &dw)) ||
+      (st = plhip_malloc(ctx, plhip_conv_packed_weight_bytes(&d), &dwp)) || (st = plhip_malloc(ctx, ref.size() * 4, &dy)))
+    return st;
+  st = plhip_memcpy_h2d(ctx, dx, hx.data(), hx.size());
+  if (!st) st = plhip_memcpy_h2d(ctx, dw, hw.data(), hw.size());
+  if (!st) st = plhip_pack_conv_weights(ctx, &d, (const int8_t*)dw, dwp);
+  if (!st) st = plhip_conv2d_int8(ctx, &d, (const int8_t*)dx, dwp, nullptr, nullptr, dy, PLHIP_OUT_I32_ACC, nullptr, 0);
+  if (!st) st = plhip_memcpy_d2h(ctx, got.data(), dy, got.size() * 4);
+  plhip_free(ctx, dx); plhip_free(ctx, dw); plhip_free(ctx, dwp); plhip_free(ctx, dy);
+  if (st) return st;
+  size_t bad = 0;
+  for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != got[i];
+  if (bad) {
+    char msg[64];
+    snprintf(msg, sizeof msg, "%zu of %zu", bad, ref.size());
+    return fail(ctx, PLHIP_ERR_HIP, "plhip_selftest: MFMA known-answer GEMM mismatched in %s accumulators", msg);
+  }
+  return PLHIP_OK;
+}
+
+}  // extern "C"

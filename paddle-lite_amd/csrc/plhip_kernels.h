@@ -1,0 +1,61 @@
+// plhip_kernels.h — argument blocks and host launchers of the gfx950 kernels (internal to libplhip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace plhip {
+
+struct GemmArgs {
+  const int8_t* wp;    // packed weights of this group: [MT32][KS][64][16]
+  const int8_t* x;     // B operand base for this group: row k of image b at x + b*x_bstride + k*HWX
+  void* y;             // output base for this group: row m of image b at y + (b*y_bstride + m*HWY) elements
+  const float* scale;  // [M] folded per-channel scale (unused for I32)
+  const float* bias;   // [M] folded bias or nullptr
+  int M, K, KS;        // rows, reduction length, K-steps of 32
+  int HWX, HWY;        // columns per image in x (pitch, multiple of 4) / valid columns per image in y
+  int NB;              // images
+  size_t x_bstride, y_bstride;
+  int MT, NT;          // wave tiles along M (32*MA rows) and N (128 columns)
+  int act;
+  float alpha;
+};
+
+struct Im2colArgs {
+  const int8_t* x;
+  int8_t* col;
+  int cin, cin_g, h, w, kh, kw, pt, pl, sh, sw, dh, dw, oh, ow;
+  int G, Kg, N, Np;
+  size_t rows;  // B*G*Kg
+};
+
+struct DwArgs {
+  const int8_t* x;
+  const int8_t* wt;  // [C][kh*kw]
+  void* y;
+  const float* scale;
+  const float* bias;
+  int planes, C, h, w, oh, ow, kh, kw, pt, pl, sh, sw, dh, dw;
+  int PB;       // planes per block
+  int OB;       // output rows per block band
+  int bands;    // bands per plane
+  int in_rows;  // staged input rows per band
+  int pitch;    // LDS row pitch in bytes (multiple of 4)
+  int act;
+  float alpha;
+};
+
+void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, hipStream_t s);
+void launch_pack_weights(const int8_t* w, int8_t* wp, int G, int Mg, int Kg, int MT32, int KS, hipStream_t s);
+void launch_im2col(const Im2colArgs& a, hipStream_t s);
+int launch_depthwise(const DwArgs& a, int out, hipStream_t s);  // returns 0 or -3 (unsupported LDS size)
+
+void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s);
+void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const float* bias, void* y, int m, int k, int n,
+               int relu, int out, hipStream_t s);
+void launch_calib_f32_to_i8(const float* x, int8_t* y, float scale, int64_t count, hipStream_t s);
+void launch_calib_i8_to_f32(const int8_t* x, float* y, float scale, int64_t count, hipStream_t s);
+void launch_global_avg_pool(const float* x, int nc, int spatial, float* y, hipStream_t s);
+void launch_softmax(const float* x, int rows, int cols, float* y, hipStream_t s);
+
+}  // namespace plhip

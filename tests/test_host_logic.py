@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library loads and exports every declared symbol; host-side bit tricks used by the
+kernels are equivalent to the oracle's libm formulation."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "plhip.h")).read()
+    declared = sorted(set(re.findall(r"\b(plhip_[a-z0-9_]+)\s*\(", hdr)))
+    assert set(declared) == set(pkg.capi.EXPORTS), set(declared) ^ set(pkg.capi.EXPORTS)
+    lib = pkg.capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_device_is_an_error_not_a_fallback(pkg):
+    lib = pkg.capi.load()
+    if lib.plhip_device_count() > 0:
+        return
+    h = ctypes.c_void_p()
+    assert lib.plhip_ctx_create(0, ctypes.byref(h)) != 0
+    try:
+        pkg.capi.Context(0)
+    except pkg.capi.PlhipError:
+        pass
+    else:
+        raise AssertionError("Context() must raise without a GPU")
+
+
+def test_descriptor_helpers(pkg):
+    capi = pkg.capi
+    lib = capi.load()
+    d = capi.conv_desc(32, 64, 56, 56, 128, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)
+    assert capi.out_hw(d) == (56, 56)
+    # C2: K = 576 -> 18 K-steps, M = 128 -> 4 fragment rows: 4*18 KiB packed
+    assert lib.plhip_conv_packed_weight_bytes(ctypes.byref(d)) == 4 * 18 * 1024
+    assert lib.plhip_conv_workspace_bytes(ctypes.byref(d)) == 32 * 576 * 3136
+    assert lib.plhip_conv_impl_name(ctypes.byref(d)) == b"conv_im2col_gemm_int8_mfma32x32x32"
+    p = capi.conv_desc(128, 512, 14, 14, 512, 1, 1)
+    assert lib.plhip_conv_workspace_bytes(ctypes.byref(p)) == 0
+    assert lib.plhip_conv_impl_name(ctypes.byref(p)) == b"conv1x1s1_gemm_int8_mfma32x32x32"
+    bad = capi.conv_desc(1, 6, 8, 8, 8, 3, 3, groups=4)  # cin % groups != 0
+    assert lib.plhip_conv_packed_weight_bytes(ctypes.byref(bad)) == 0
+
+
+def test_round_half_away_integer_trick(plref):
+    """Device epilogue: q = (t + 1 + (t>>31)) >> 1, t = trunc(clamp(2y, -254, 254)) == clamp(roundf(y))."""
+    rng = np.random.default_rng(5)
+    y = np.concatenate([
+        rng.uniform(-140, 140, 200000).astype(np.float32),
+        (rng.integers(-300, 300, 20000) / 2.0).astype(np.float32),  # exact ties
+        np.nextafter(np.float32(0.5), np.float32(0)).reshape(1), np.nextafter(np.float32(-0.5), np.float32(0)).reshape(1),
+        np.nextafter((rng.integers(-260, 260, 20000) / 2.0).astype(np.float32), np.float32(1e9)),
+        np.nextafter((rng.integers(-260, 260, 20000) / 2.0).astype(np.float32), np.float32(-1e9)),
+        np.array([0.0, -0.0, 127.49999, 127.5, -127.5, 1e30, -1e30, np.inf, -np.inf], np.float32),
+    ]).astype(np.float32)
+    y2 = np.clip(y + y, np.float32(-254), np.float32(254))
+    t = np.trunc(y2).astype(np.int32)
+    q = (t + 1 + (t >> 31)) >> 1
+    lib = plref.lib()
+    ref = np.array([lib.plref_round_sat_i8(ctypes.c_float(v)) for v in y[:5000]], np.int32)
+    assert np.array_equal(q[:5000], ref)
+    # vectorised check of the rest through the calib oracle (scale 1 => q = round_sat(y))
+    assert np.array_equal(q, plref.calib_f32_to_i8(y, 1.0).astype(np.int32))
