@@ -52,8 +52,8 @@ def conv_desc(n, cin, h, w, cout, kh, kw, pad=(0, 0, 0, 0), stride=(1, 1), dil=(
 def out_hw(d):
     keh = d.dil[0] * (d.kh - 1) + 1
     kew = d.dil[1] * (d.kw - 1) + 1
-    return ((d.h + d.pad[0] + d.pad[1] - keh) // d.stride[0] + 1,
-            (d.w + d.pad[2] + d.pad[3] - kew) // d.stride[1] + 1)
+    return (int((d.h + d.pad[0] + d.pad[1] - keh) / d.stride[0]) + 1,
+            int((d.w + d.pad[2] + d.pad[3] - kew) / d.stride[1]) + 1)
 
 
 class PlhipError(RuntimeError):

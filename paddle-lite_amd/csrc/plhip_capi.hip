@@ -58,9 +58,11 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   // conv_int8_compute_test.cc:67-88
   const int keh = d->dil[0] * (d->kh - 1) + 1, kew = d->dil[1] * (d->kw - 1) + 1;
   const int hn = d->h + d->pad[0] + d->pad[1] - keh, wn = d->w + d->pad[2] + d->pad[3] - kew;
-  if (hn < 0 || wn < 0) return false;
+  // C integer division (truncation), exactly as the reference computes it; a kernel extent larger than
+  // the padded input is legal there as long as the quotient still yields >= 1 output.
   g->oh = hn / d->stride[0] + 1;
   g->ow = wn / d->stride[1] + 1;
+  if (g->oh < 1 || g->ow < 1) return false;
   g->G = d->groups;
   g->Mg = d->cout / d->groups;
   g->Cg = d->cin / d->groups;

@@ -1,0 +1,206 @@
+// conv_compute.cc — TARGET(kHIP) / PRECISION(kInt8) conv2d + depthwise_conv2d kernels.
+//
+// Mirrors lite/kernels/arm/conv_compute.cc:87-185 (impl selection), conv_gemmlike.cc:85-264 and
+// conv_depthwise.cc:138-296 (shape-change re-init, weight pre-pack, scale / bias / relu6 folding) and the six
+// registrations of conv_compute.cc:216-252.  Differences by design: 3x3s1 goes through the
+// direct accumulator (im2col GEMM), not the integer Winograd transform, and 3x3s2 needs no special DirectConv.
+#include "lite/kernels/hip/conv_compute.h"
+
+#include "lite/core/op_registry.h"
+
+namespace paddle {
+namespace lite {
+namespace kernels {
+namespace hip {
+
+namespace {
+const void* DeviceCopyOf(const Tensor* src, Tensor* holder, size_t bytes) {
+  // Persistable params may still live on the host (the reference moves them with an io_copy_once
+  // instruction inserted by type_target_cast_pass); upload once if so.
+  if (src->target() == TARGET(kHIP)) return src->raw_data();
+  void* d = holder->mutable_data(TARGET(kHIP), bytes);
+  TargetWrapperHip::MemcpySync(d, src->raw_data(), bytes, IoDirection::HtoD);
+  return d;
+}
+}  // namespace
+
+template <PrecisionType Ptype, PrecisionType OutType>
+void ConvCompute<Ptype, OutType>::BuildDesc() {
+  auto& param = this->template Param<param_t>();
+  const auto x = param.x->dims(), w = param.filter->dims();
+  CHECK_EQ(x.size(), 4UL);
+  CHECK(param.paddings && param.paddings->size() == 4UL) << "paddings must be {top, bottom, left, right}";
+  CHECK(param.dilations && param.dilations->size() == 2UL);
+  desc_.n = static_cast<int>(x[0]);
+  desc_.cin = static_cast<int>(x[1]);
+  desc_.h = static_cast<int>(x[2]);
+  desc_.w = static_cast<int>(x[3]);
+  desc_.cout = static_cast<int>(w[0]);
+  desc_.kh = static_cast<int>(w[2]);
+  desc_.kw = static_cast<int>(w[3]);
+  for (int i = 0; i < 4; ++i) desc_.pad[i] = (*param.paddings)[i];
+  desc_.stride[0] = param.strides[0];
+  desc_.stride[1] = param.strides[1];
+  desc_.dil[0] = (*param.dilations)[0];
+  desc_.dil[1] = (*param.dilations)[1];
+  desc_.groups = param.groups;
+}
+
+template <PrecisionType Ptype, PrecisionType OutType>
+void ConvCompute<Ptype, OutType>::ReInitWhenNeeded() {
+  auto& param = this->template Param<param_t>();
+  if (last_shape_ == param.x->dims()) return;  // conv_gemmlike.cc:92 idiom
+  BuildDesc();
+  workspace_bytes_ = is_depthwise_ ? 0 : plhip_conv_workspace_bytes(&desc_);
+  last_shape_ = param.x->dims();
+}
+
+template <PrecisionType Ptype, PrecisionType OutType>
+void ConvCompute<Ptype, OutType>::PrepareForRun() {
+  auto& param = this->template Param<param_t>();
+  CHECK(this->ctx_) << "SetContext must precede PrepareForRun";
+  auto& ctx = this->ctx_->template As<HIPContext>();
+  const auto w_dims = param.filter->dims();
+  const int oc = static_cast<int>(w_dims[0]);
+  const int ic = static_cast<int>(w_dims[1]) * param.groups;
+  BuildDesc();
+
+  // ---- impl selection (conv_compute.cc:87-134): depthwise iff groups == ic == oc; everything else is GEMM-like
+  is_depthwise_ = param.groups == ic && ic == oc && param.groups > 1;
+
+  // ---- activation (conv_gemmlike.cc:325-345 reads activation_param; fuse_relu is the legacy flag)
+  const auto& act = param.activation_param;
+  desc_.act = PLHIP_ACT_NONE;
+  act_alpha_ = 0.f;
+  if (act.has_active) {
+    switch (act.active_type) {
+      case lite_api::ActivationType::kRelu: desc_.act = PLHIP_ACT_RELU; break;
+      case lite_api::ActivationType::kRelu6:
+        desc_.act = PLHIP_ACT_RELU6;
+        act_alpha_ = act.Relu_clipped_coef;
+        break;
+      case lite_api::ActivationType::kLeakyRelu:
+        desc_.act = PLHIP_ACT_LEAKY_RELU;
+        act_alpha_ = act.Leaky_relu_alpha;
+        break;
+      default: LOG(FATAL) << "this act_type: " << static_cast<int>(act.active_type) << " fuse not support";
+    }
+  } else if (param.fuse_relu) {
+    desc_.act = PLHIP_ACT_RELU;
+  }
+
+  // ---- scale / bias folding: conv_gemmlike.cc:208-263, conv_depthwise.cc:146-158,242-271 (fp32, as written)
+  std::vector<float> w_scale = param.weight_scale;
+  if (w_scale.size() != 1 && w_scale.size() != static_cast<size_t>(oc)) {
+    LOG(FATAL) << "weights scale size must equal to filter size";
+  }
+  if (w_scale.size() == 1) w_scale.resize(oc, w_scale[0]);
+  const float in_scale = param.input_scale, out_scale = param.output_scale;
+  constexpr bool kInt8Out = OutType == PRECISION(kInt8);
+  for (auto& ws : w_scale) {
+    if (kInt8Out) ws = ws * in_scale / out_scale;
+    else ws = ws * in_scale;
+  }
+  float* ds = scale_.mutable_data<float>(TARGET(kHIP));  // sized below
+  (void)ds;
+  scale_.Resize({oc});
+  TargetWrapperHip::MemcpySync(scale_.mutable_data<float>(TARGET(kHIP)), w_scale.data(), oc * sizeof(float),
+                               IoDirection::HtoD);
+  has_bias_ = param.bias != nullptr;
+  if (has_bias_) {
+    CHECK_EQ(param.bias->numel(), oc) << "bias size must equal to filter number";
+    std::vector<float> b(oc);
+    TargetCopy(TARGET(kHost), param.bias->target(), b.data(), param.bias->raw_data(), oc * sizeof(float));
+    if (kInt8Out)
+      for (auto& v : b) v = v / out_scale;
+    bias_.Resize({oc});
+    TargetWrapperHip::MemcpySync(bias_.mutable_data<float>(TARGET(kHIP)), b.data(), oc * sizeof(float), IoDirection::HtoD);
+  }
+  if (kInt8Out && desc_.act == PLHIP_ACT_RELU6) act_alpha_ = act_alpha_ / out_scale;  // conv_gemmlike.cc:259-263
+  desc_.act_alpha = act_alpha_;
+
+  // ---- weights: pre-pack once (trans_gemm_weights<kInt8> -> prepackA_int8 analogue), or keep OIHW for depthwise
+  Tensor staged;
+  const size_t w_bytes = static_cast<size_t>(param.filter->numel());
+  const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(param.filter, &staged, w_bytes));
+  if (is_depthwise_) {
+    void* d = weights_.mutable_data(TARGET(kHIP), w_bytes);
+    TargetWrapperHip::MemcpySync(d, w_dev, w_bytes, IoDirection::DtoD);
+    kernel_func_name_ = std::string("conv_depthwise_") + std::to_string(desc_.kh) + "x" + std::to_string(desc_.kw) +
+                        (kInt8Out ? "_int8_int8_hip" : "_int8_fp32_hip");
+  } else {
+    const size_t packed = plhip_conv_packed_weight_bytes(&desc_);
+    CHECK_GT(packed, 0UL) << "invalid conv configuration";
+    void* d = weights_.mutable_data(TARGET(kHIP), packed);
+    HIP_CALL(ctx.ctx(), plhip_pack_conv_weights(ctx.ctx(), &desc_, w_dev, d));
+    ctx.Sync();  // `staged` dies at scope exit
+    kernel_func_name_ = plhip_conv_impl_name(&desc_);
+  }
+  last_shape_ = DDim();
+  ReInitWhenNeeded();
+}
+
+template <PrecisionType Ptype, PrecisionType OutType>
+void ConvCompute<Ptype, OutType>::Run() {
+  auto& param = this->template Param<param_t>();
+  auto& ctx = this->ctx_->template As<HIPContext>();
+  CHECK(param.x->target() == TARGET(kHIP)) << "conv input must live on the HIP device (io_copy missing?)";
+  const int8_t* x = param.x->template data<int8_t>();
+  const float* sc = scale_.data<float>();
+  const float* bi = has_bias_ ? bias_.data<float>() : nullptr;
+  void* y;
+  plhip_out_kind kind;
+  if (OutType == PRECISION(kInt8)) {
+    y = param.output->template mutable_data<int8_t>(TARGET(kHIP));
+    kind = PLHIP_OUT_I8;
+  } else {
+    y = param.output->template mutable_data<float>(TARGET(kHIP));
+    kind = PLHIP_OUT_F32;
+  }
+  if (is_depthwise_) {
+    HIP_CALL(ctx.ctx(), plhip_depthwise_conv_int8(ctx.ctx(), &desc_, x, weights_.data<int8_t>(), sc, bi, y, kind));
+  } else {
+    void* ws = workspace_bytes_ ? ctx.workspace(workspace_bytes_) : nullptr;
+    HIP_CALL(ctx.ctx(), plhip_conv2d_int8(ctx.ctx(), &desc_, x, weights_.raw_data(), sc, bi, y, kind, ws, workspace_bytes_));
+  }
+}
+
+template class ConvCompute<PRECISION(kInt8), PRECISION(kInt8)>;
+template class ConvCompute<PRECISION(kInt8), PRECISION(kFloat)>;
+
+}  // namespace hip
+}  // namespace kernels
+}  // namespace lite
+}  // namespace paddle
+
+typedef paddle::lite::kernels::hip::ConvCompute<PRECISION(kInt8), PRECISION(kFloat)> ConvInt8_Fp32;
+typedef paddle::lite::kernels::hip::ConvCompute<PRECISION(kInt8), PRECISION(kInt8)> ConvInt8_Int8;
+
+// Same argument names, precisions and aliases as lite/kernels/arm/conv_compute.cc:216-252, target kHIP.
+REGISTER_LITE_KERNEL(conv2d, kHIP, kInt8, kNCHW, ConvInt8_Int8, int8_out)
+    .BindInput("Input", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindInput("Bias", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kFloat))})
+    .BindInput("Filter", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindOutput("Output", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .Finalize();
+
+REGISTER_LITE_KERNEL(conv2d, kHIP, kInt8, kNCHW, ConvInt8_Fp32, fp32_out)
+    .BindInput("Input", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindInput("Bias", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kFloat))})
+    .BindInput("Filter", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindOutput("Output", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kFloat))})
+    .Finalize();
+
+REGISTER_LITE_KERNEL(depthwise_conv2d, kHIP, kInt8, kNCHW, ConvInt8_Int8, int8_out)
+    .BindInput("Input", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindInput("Bias", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kFloat))})
+    .BindInput("Filter", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindOutput("Output", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .Finalize();
+
+REGISTER_LITE_KERNEL(depthwise_conv2d, kHIP, kInt8, kNCHW, ConvInt8_Fp32, fp32_out)
+    .BindInput("Input", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindInput("Bias", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kFloat))})
+    .BindInput("Filter", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindOutput("Output", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kFloat))})
+    .Finalize();

@@ -1,0 +1,44 @@
+// conv_compute.h — ConvCompute<PRECISION(kInt8), OutType> for TARGET(kHIP): the drop-in for
+// lite/kernels/arm/conv_compute.h:27-58 (+ conv_gemmlike / conv_depthwise / conv_direct / conv_winograd,
+// which collapse into two device paths here: MFMA GEMM and depthwise).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "lite/core/kernel.h"
+#include "lite/operators/op_params.h"
+#include "plhip.h"
+
+namespace paddle {
+namespace lite {
+namespace kernels {
+namespace hip {
+
+template <PrecisionType Ptype, PrecisionType OutType>
+class ConvCompute : public KernelLite<TARGET(kHIP), Ptype> {
+ public:
+  using param_t = operators::ConvParam;
+  void PrepareForRun() override;
+  void ReInitWhenNeeded() override;
+  void Run() override;
+  std::string kernel_func_name() const override { return kernel_func_name_; }
+  ~ConvCompute() override = default;
+
+ private:
+  void BuildDesc();
+  plhip_conv_desc desc_{};
+  bool is_depthwise_{false};
+  DDim last_shape_;
+  Tensor weights_;   // packed (GEMM path) or raw OIHW (depthwise path), on device
+  Tensor scale_;     // folded per-channel scale, device
+  Tensor bias_;      // folded bias, device (only if param.bias)
+  bool has_bias_{false};
+  float act_alpha_{0.f};
+  size_t workspace_bytes_{0};
+  std::string kernel_func_name_{"NotImplForConv"};
+};
+
+}  // namespace hip
+}  // namespace kernels
+}  // namespace lite
+}  // namespace paddle

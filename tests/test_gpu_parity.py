@@ -1,0 +1,255 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libplhip.so), against the CPU oracle on
+identical seeded inputs and against the committed golden vectors.
+
+Bar: int32 accumulators bit-exact; int8 outputs bit-exact vs the oracle's restatement of the reference
+epilogue; fp32 outputs within 1e-5 relative (north_star) — in practice they are bit-identical because
+both sides use a single fused multiply-add.  Sweep grids mirror lite/tests/math/conv_int8_compute_test.cc:
+482-731 (thinned to keep one process / a few minutes).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FP32_RTOL = 1e-5  # north_star: "within 1e-5 after float dequant"
+
+
+def _check_all_kinds(ctx, capi, plref, n, cin, h, w, cout, kh, kw, pads, st, dl, g, act, alpha, has_bias, rng,
+                     depthwise=False, per_channel=True):
+    s = plref.shape(n, cin, h, w, cout, kh, kw, pads, (st, st), (dl, dl), g)
+    oh, ow = plref.out_dims(s)
+    if oh < 1 or ow < 1:
+        return 0
+    x = rng.integers(-127, 128, (n, cin, h, w)).astype(np.int8)
+    wt = rng.integers(-127, 128, (cout, cin // g, kh, kw)).astype(np.int8)
+    bias = rng.uniform(-1, 1, cout).astype(np.float32) if has_bias else None
+    kk = (cin // g) * kh * kw
+    in_scale = 1.0 / 127
+    w_scale = ((1 + np.arange(cout) % 7) / 127.0 / 4.0).astype(np.float32) if per_channel else np.array([1 / 127.0], np.float32)
+    out_scale = kk / 127.0 if act != 2 else alpha / 127.0
+    acc_ref = plref.conv2d_acc(s, x, wt)
+    d = capi.conv_desc(n, cin, h, w, cout, kh, kw, pads, (st, st), (dl, dl), g, act, alpha)
+    acc = ctx.conv2d(d, x, wt, None, None, capi.OUT_I32, depthwise=depthwise)
+    assert np.array_equal(acc, acc_ref), "int32 accumulators differ"
+    for int8_out, kind in ((0, capi.OUT_F32), (1, capi.OUT_I8)):
+        sc, bi, al = plref.fold_scales(int8_out, in_scale, w_scale, out_scale, bias, cout, act, alpha)
+        d.act_alpha = al
+        y_ref = plref.epilogue(acc_ref, sc, bi, act, al, bool(int8_out))
+        y = ctx.conv2d(d, x, wt, sc, bi if has_bias else None, kind, depthwise=depthwise)
+        if int8_out:
+            assert np.array_equal(y, y_ref), "int8 output differs"
+        else:
+            np.testing.assert_allclose(y, y_ref, rtol=FP32_RTOL, atol=1e-6)
+    return 1
+
+
+def test_selftest_known_answer(gpu_ctx):
+    gpu_ctx.selftest()
+
+
+CONV = golden_files("conv_")
+
+
+@pytest.mark.parametrize("path", CONV, ids=[os.path.basename(p)[5:-4] for p in CONV])
+def test_conv_golden(gpu_ctx, pkg, plref, path):
+    capi = pkg.capi
+    g = load_golden(path)
+    n, cin, h, w = g["x"].shape
+    cout, _, kh, kw = g["w"].shape
+    st, dl, grp = int(g["stride"]), int(g["dil"]), int(g["groups"])
+    act, alpha = int(g["act"]), float(g["alpha"])
+    pads = tuple(int(p) for p in g["pads"])
+    bias = g.get("bias")
+    dw = grp == cin == cout and grp > 1
+    d = capi.conv_desc(n, cin, h, w, cout, kh, kw, pads, (st, st), (dl, dl), grp, act, alpha)
+    for depthwise in ([True, False] if dw and grp <= 8 else [dw]):
+        acc = gpu_ctx.conv2d(d, g["x"], g["w"], None, None, capi.OUT_I32, depthwise=depthwise)
+        assert np.array_equal(acc, g["acc_ref"])  # acc_ref comes from the reference's conv_basic<int8,int>
+        for int8_out, kind, key in ((0, capi.OUT_F32, "y_f32"), (1, capi.OUT_I8, "y_i8")):
+            sc, bi, al = plref.fold_scales(int8_out, float(g["in_scale"]), g["w_scale"], float(g["out_scale"]), bias, cout, act, alpha)
+            d.act_alpha = al
+            y = gpu_ctx.conv2d(d, g["x"], g["w"], sc, bi if bias is not None else None, kind, depthwise=depthwise)
+            if int8_out:
+                assert np.array_equal(y, g[key])
+            else:
+                np.testing.assert_allclose(y, g[key], rtol=FP32_RTOL, atol=1e-6)
+
+
+@pytest.mark.parametrize("path", golden_files("gemm_"), ids=lambda p: os.path.basename(p)[5:-4])
+def test_gemm_golden_as_1x1_conv(gpu_ctx, pkg, path):
+    """basic_gemm<int8,int> golden: C = A(MxK) * B(KxN) == 1x1 conv with cout=M, cin=K, HW=N."""
+    capi = pkg.capi
+    g = load_golden(path)
+    m, k = g["a"].shape
+    n = g["b"].shape[1]
+    d = capi.conv_desc(1, k, 1, n, m, 1, 1)
+    acc = gpu_ctx.conv2d(d, g["b"].reshape(1, k, 1, n), g["a"].reshape(m, k, 1, 1), None, None, capi.OUT_I32)
+    assert np.array_equal(acc.reshape(m, n), g["acc_ref"])
+
+
+def test_dw3x3_sweep(gpu_ctx, pkg, plref):
+    """conv_int8_compute_test.cc:482-513 (thinned)."""
+    rng = np.random.default_rng(100)
+    cnt = 0
+    for st in (1, 2):
+        for pad in (0, 1):
+            for c in (1, 3, 5, 8, 16, 32):
+                for h in (1, 3, 15, 33):
+                    act = (0, 1, 2, 4)[cnt % 4]
+                    cnt += _check_all_kinds(gpu_ctx, pkg.capi, plref, 1 + cnt % 2, c, h, h, c, 3, 3, (pad,) * 4, st, 1, c,
+                                            act, 6.0 if act == 2 else 0.3, cnt % 2 == 0, rng, depthwise=True) or 1
+    assert cnt > 40
+
+
+def test_dw5x5_sweep(gpu_ctx, pkg, plref):
+    """conv_int8_compute_test.cc:517-548 (thinned)."""
+    rng = np.random.default_rng(101)
+    cnt = 0
+    for st in (1, 2):
+        for pad in (0, 1, 2, 3, 4):
+            for c in (1, 5, 15, 33):
+                for h in (3, 15, 33, 112):
+                    if h == 112 and c > 5:
+                        continue
+                    act = (0, 1, 2, 4)[cnt % 4]
+                    cnt += _check_all_kinds(gpu_ctx, pkg.capi, plref, 1 + cnt % 2, c, h, h, c, 5, 5, (pad,) * 4, st, 1, c,
+                                            act, 6.0 if act == 2 else 0.3, cnt % 2 == 1, rng, depthwise=True) or 1
+    assert cnt > 40
+
+
+def test_dw_generic_path_dilated_and_rect(gpu_ctx, pkg, plref):
+    rng = np.random.default_rng(102)
+    for (c, h, w, kh, kw, st, dl, pads) in [(4, 13, 11, 3, 3, 1, 2, (2, 2, 2, 2)), (3, 9, 17, 2, 3, 2, 1, (0, 1, 1, 0)),
+                                           (6, 12, 12, 7, 7, 1, 1, (3, 3, 3, 3)), (2, 8, 8, 1, 1, 1, 1, (0, 0, 0, 0))]:
+        s_ok = _check_all_kinds(gpu_ctx, pkg.capi, plref, 2, c, h, w, c, kh, kw, pads, st, dl, c, 1, 0.0, True, rng, depthwise=True)
+        assert s_ok == 1
+
+
+def test_conv1x1s1_sweep(gpu_ctx, pkg, plref):
+    """conv_int8_compute_test.cc:552-586."""
+    rng = np.random.default_rng(103)
+    cnt = 0
+    for cin in (1, 3, 8, 33):
+        for cout in (1, 5, 17):
+            for g in (1, 2):
+                if cin % g or cout % g:
+                    continue
+                for h in (1, 9, 16, 33):
+                    act = (0, 1, 2, 4)[cnt % 4]
+                    cnt += _check_all_kinds(gpu_ctx, pkg.capi, plref, 1 + cnt % 2, cin, h, h, cout, 1, 1, (0, 0, 0, 0), 1, 1, g,
+                                            act, 6.0 if act == 2 else 0.3, cnt % 2 == 0, rng)
+    assert cnt > 30
+
+
+def test_conv3x3_s1_s2_asymmetric_pads(gpu_ctx, pkg, plref):
+    """conv_int8_compute_test.cc:590-673 (thinned)."""
+    rng = np.random.default_rng(104)
+    cnt = 0
+    for st in (1, 2):
+        for cin in (1, 3, 8, 33):
+            for cout in (1, 5, 33):
+                for pads in ((1, 1, 1, 1), (1, 2, 2, 1), (2, 1, 1, 2), (2, 2, 2, 2)):
+                    h = (1, 7, 17, 33)[cnt % 4]
+                    act = (0, 1, 2, 4)[(cnt // 2) % 4]
+                    cnt += _check_all_kinds(gpu_ctx, pkg.capi, plref, 1 + cnt % 2, cin, h, h, cout, 3, 3, pads, st, 1, 1,
+                                            act, 6.0 if act == 2 else 0.3, cnt % 2 == 0, rng) or 1
+    assert cnt > 60
+
+
+def test_conv_random_params(gpu_ctx, pkg, plref):
+    """conv_int8_compute_test.cc:677-730 (seeded random subset of the grid)."""
+    rng = np.random.default_rng(105)
+    done = 0
+    for _ in range(120):
+        cin = int(rng.choice([1, 17, 8]))
+        cout = int(rng.choice([1, 8, 17]))
+        g = int(rng.choice([1, 2]))
+        if cin % g or cout % g:
+            continue
+        kh, kw = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        st, dl = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        pads = tuple(int(v) for v in rng.integers(0, 3, 4))
+        h = int(rng.choice([1, 3, 5, 19]))
+        act = int(rng.choice([0, 1, 2, 4]))
+        done += _check_all_kinds(gpu_ctx, pkg.capi, plref, int(rng.integers(1, 3)), cin, h, h, cout, kh, kw, pads, st, dl, g,
+                                 act, 6.0 if act == 2 else 0.3, bool(rng.integers(0, 2)), rng, per_channel=bool(rng.integers(0, 2)))
+    assert done > 40
+
+
+def test_gemm_grid_as_1x1(gpu_ctx, pkg, plref):
+    """gemm_int8_compute_test.cc:350-357 grid (M x N x K tails), via the 1x1 path incl. N % 4 != 0 (im2col route)."""
+    rng = np.random.default_rng(106)
+    capi = pkg.capi
+    for m in (1, 3, 8, 32, 33, 35, 41, 397):
+        for n in (1, 3, 13, 141, 512):
+            k = int(rng.choice([1, 3, 8, 59, 60, 62, 67, 71]))
+            a = rng.integers(-127, 128, (m, k)).astype(np.int8)
+            b = rng.integers(-127, 128, (k, n)).astype(np.int8)
+            d = capi.conv_desc(1, k, 1, n, m, 1, 1)
+            acc = gpu_ctx.conv2d(d, b.reshape(1, k, 1, n), a.reshape(m, k, 1, 1), None, None, capi.OUT_I32)
+            assert np.array_equal(acc.reshape(m, n), plref.gemm_acc(a, b)), (m, n, k)
+
+
+def test_mobilenet_layer_shapes_small_batch(gpu_ctx, pkg, plref):
+    """Appendix B shapes (pointwise + depthwise + first conv), batch 2, int8 out with relu."""
+    rng = np.random.default_rng(107)
+    capi = pkg.capi
+    for (cin, cout, hw) in [(32, 64, 112), (64, 128, 56), (128, 128, 56), (256, 256, 28), (512, 512, 14), (512, 1024, 7), (1024, 1024, 7)]:
+        n = 2 if hw <= 56 else 1
+        assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, hw, hw, cout, 1, 1, (0, 0, 0, 0), 1, 1, 1, 1, 0.0, True, rng) == 1
+    for (c, hw, st) in [(32, 112, 1), (64, 112, 2), (128, 56, 1), (256, 28, 2), (512, 14, 1), (1024, 7, 1)]:
+        assert _check_all_kinds(gpu_ctx, capi, plref, 2, c, hw, hw, c, 3, 3, (1, 1, 1, 1), st, 1, c, 1, 0.0, True, rng, depthwise=True) == 1
+    assert _check_all_kinds(gpu_ctx, capi, plref, 1, 3, 224, 224, 32, 3, 3, (1, 1, 1, 1), 2, 1, 1, 1, 0.0, True, rng) == 1
+
+
+def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
+    capi = pkg.capi
+    g = load_golden(golden_files("fc_")[0])
+    assert np.array_equal(gpu_ctx.fc(g["x"], g["w"], None, None, 0, capi.OUT_I32), g["acc_ref"])
+    np.testing.assert_allclose(gpu_ctx.fc(g["x"], g["w"], g["scale"], g["bias"], 1, capi.OUT_F32), g["y_f32"], rtol=FP32_RTOL, atol=1e-7)
+    assert np.array_equal(gpu_ctx.fc(g["x"], g["w"], g["scale8"], g["bias8"], 1, capi.OUT_I8), g["y_i8"])
+    rng = np.random.default_rng(108)
+    # fc_compute.cc shapes: MobileNet tail (k=1024, n=1000) at a ragged batch; k % 4 != 0 tail
+    for (m, k, n) in [(5, 1024, 1000), (1, 7, 3), (17, 66, 257)]:
+        x = rng.integers(-127, 128, (m, k)).astype(np.int8)
+        w = rng.integers(-127, 128, (k, n)).astype(np.int8)
+        sc = ((1 + np.arange(n) % 5) / 127.0 / 127.0).astype(np.float32)
+        bi = rng.uniform(-1, 1, n).astype(np.float32)
+        y_ref, acc_ref = plref.fc(x, w, bi, sc, False, False)
+        assert np.array_equal(gpu_ctx.fc(x, w, None, None, 0, capi.OUT_I32), acc_ref)
+        np.testing.assert_allclose(gpu_ctx.fc(x, w, sc, bi, 0, capi.OUT_F32), y_ref, rtol=FP32_RTOL, atol=1e-7)
+    c = load_golden(golden_files("calib")[0])
+    assert np.array_equal(gpu_ctx.calib_f32_to_i8(c["x"], float(c["scale"])), c["q"])
+    assert np.array_equal(gpu_ctx.calib_i8_to_f32(c["q"], float(c["scale"])), c["deq"])
+    xf = rng.uniform(-4, 4, (3, 5, 7, 9)).astype(np.float32)
+    assert np.array_equal(gpu_ctx.calib_f32_to_i8(xf, 1 / 31.0), plref.calib_f32_to_i8(xf, 1 / 31.0))
+    xp = rng.uniform(-1, 1, (3, 20, 7, 7)).astype(np.float32)
+    np.testing.assert_allclose(gpu_ctx.global_avg_pool(xp), plref.global_avg_pool(xp), rtol=1e-5, atol=1e-6)
+    xs = rng.uniform(-5, 5, (4, 1000)).astype(np.float32)
+    np.testing.assert_allclose(gpu_ctx.softmax(xs), plref.softmax(xs), rtol=1e-5, atol=1e-7)
+
+
+def test_full_size_properties_c2(gpu_ctx, pkg, plref):
+    """BASELINE config #2 at full size (N=32, 64->128, 56x56, k3 s1 p1): too big for the scalar oracle in
+    seconds, so check size-independent properties: (i) linearity in the weights acc(w1+w2) = acc(w1)+acc(w2);
+    (ii) batch independence (image b alone gives the same slice); (iii) a sampled set of outputs vs the oracle."""
+    capi = pkg.capi
+    rng = np.random.default_rng(109)
+    n, cin, cout, hw = 32, 64, 128, 56
+    x = rng.integers(-127, 128, (n, cin, hw, hw)).astype(np.int8)
+    w1 = rng.integers(-63, 64, (cout, cin, 3, 3)).astype(np.int8)
+    w2 = rng.integers(-63, 64, (cout, cin, 3, 3)).astype(np.int8)
+    d = capi.conv_desc(n, cin, hw, hw, cout, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)
+    a1 = gpu_ctx.conv2d(d, x, w1, None, None, capi.OUT_I32)
+    a2 = gpu_ctx.conv2d(d, x, w2, None, None, capi.OUT_I32)
+    a12 = gpu_ctx.conv2d(d, x, (w1 + w2).astype(np.int8), None, None, capi.OUT_I32)
+    assert np.array_equal(a12, a1 + a2)
+    d1 = capi.conv_desc(1, cin, hw, hw, cout, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)
+    b = 17
+    assert np.array_equal(gpu_ctx.conv2d(d1, x[b:b + 1], w1, None, None, capi.OUT_I32)[0], a1[b])
+    s1 = plref.shape(1, cin, hw, hw, cout, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)
+    assert np.array_equal(plref.conv2d_acc(s1, x[3:4], w1)[0], a1[3])
