@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — INT8 images/sec of the MobileNetV1 224x224 graph on N MI355X GPUs (BASELINE.json metric).
+
+A step = one pass of the hot path (calib -> 27 int8 convs -> pool -> calib -> fc -> softmax, the program of
+SURVEY.md Appendix D) over one synthetic batch per GPU, through the C++ kHIP kernel classes and libplhip.so.
+Inputs are resident in HBM when the timed region starts (the host->device io_copy instruction is skipped).
+N > 1: one process per GPU (torch.distributed, backend "nccl" == RCCL): rank 0's weights are broadcast over xGMI
+at init, every rank runs its own batch shard (no collective inside the layer loop) and the logits are all-gathered
+each step.  Weak scaling: the per-GPU batch is fixed.
+
+The JSON line carries `roofline` for the dominant kernel family (time measured live with HIP events on the launch
+stream, one event pair per launch) and `cpu_baseline` (the oracle's im2col+GEMM port of the reference algorithm,
+OpenMP on the host cores, bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Denominators (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8.0 TB/s spec; int8 MFMA dense =
+# 2x the bf16 rate = 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz = 5.03 POP/s (sparsity figures not used).
+HBM_PEAK_GBS = 8000.0
+MFMA_I8_PEAK_TOPS = 256 * 4 * 2048 * 2.4e9 / 1e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE config: batch=128 on 1 GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--layer-table", action="store_true", help="print the per-layer timing table to stderr")
+    return ap.parse_args()
+
+
+def layer_costs(wl, batch):
+    """Algorithmic ops / bytes per instruction family for one step (unique in + weights + out once)."""
+    fam = {}
+    for (name, op, cin, cout, k, s, p, g, hin) in wl.mobilenet_v1_layers():
+        ho = (hin + 2 * p - k) // s + 1
+        macs = batch * ho * ho * cout * (cin // g) * k * k
+        out_b = 4 if name == "pw14" else 1
+        byts = batch * (cin * hin * hin + cout * ho * ho * out_b) + cout * (cin // g) * k * k
+        key = "conv3x3s2_first" if name == "conv1" else ("depthwise3x3" if g > 1 else "pointwise1x1")
+        fam.setdefault(key, {"ops": 0, "bytes": 0, "names": []})
+        fam[key]["ops"] += 2 * macs
+        fam[key]["bytes"] += byts
+        fam[key]["names"].append(name)
+    return fam
+
+
+def cpu_baseline(wl, W, seconds):
+    """The reference algorithm restated for the host (oracle/plref.c): im2col + int8 GEMM over (batch, group) for the
+    dense convs (conv_impl.cc:490-598 structure), direct loops for depthwise, fused float epilogue; OpenMP."""
+    from oracle import plref
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    rng = np.random.default_rng(99)
+    layers = wl.mobilenet_v1_layers()
+    done, t0 = 0, time.perf_counter()
+    while True:
+        x = plref.calib_f32_to_i8(rng.uniform(-1, 1, (1, 3, 224, 224)).astype(np.float32), float(W["input_scale"]))
+        for i, (name, op, cin, cout, k, s, p, g, hin) in enumerate(layers):
+            L = W[name]
+            sh = plref.shape(1, cin, x.shape[2], x.shape[3], cout, k, k, (p, p, p, p), (s, s), (1, 1), g)
+            x, _ = plref.conv2d(sh, x, L["w"], L["bias"], float(L["in_scale"]), L["w_scale"], float(L["out_scale"]), 1, 0.0,
+                                i != len(layers) - 1, via_gemm=(g == 1))
+        pool = plref.global_avg_pool(x)
+        q = plref.calib_f32_to_i8(pool, float(W["pool_scale"]))
+        F = W["fc"]
+        logits, _ = plref.fc(q.reshape(1, -1), F["w"], F["bias"], (F["w_scale"] * np.float32(F["in_scale"])).astype(np.float32), False, False)
+        plref.softmax(logits)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 256:
+            break
+    return {"value": round(done / el, 2), "unit": "img/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+            "kind": "port",
+            "sample": "%d images of the same MobileNetV1-INT8 graph, batch 1 each, %.1f s; oracle/plref.c restatement of the "
+                      "reference's im2col+GEMM int8 path (its ARM NEON kernels cannot run on x86; its x86 backend has no "
+                      "INT8 kernels)" % (done, el)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    ge.import_package()
+    lite = importlib.import_module("paddle_lite_amd.liteapi")
+    wl = importlib.import_module("paddle_lite_amd.workloads")
+    sharding = importlib.import_module("paddle_lite_amd.sharding")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- weights: rank 0 generates, RCCL broadcast over xGMI, every rank builds its predictor from the bytes ----
+    W = wl.make_mobilenet_v1_weights(seed=1234) if rank == 0 else None
+    W = sharding.broadcast_weights(W, dist, dev, rank, world)
+
+    stream = torch.cuda.current_stream(dev)
+    pred = lite.Predictor(local_rank, stream=stream.cuda_stream)
+    out_name = wl.build_mobilenet_v1(pred, W, args.batch)
+    rng = np.random.default_rng(1000 + rank)
+    pred.set_input("image", rng.uniform(-1, 1, (args.batch, 3, 224, 224)).astype(np.float32))
+    pred.run(skip_io_copy=False)  # first run: uploads the feed, PrepareForRun (weight pack, scale fold) everywhere
+    pred.sync()
+    n_inst = pred.num_instructions()
+    names = pred.kernel_names()
+    io_idx = [i for i, n in enumerate(names) if n.startswith("io_copy")]
+    body = [i for i in range(n_inst) if i not in io_idx]
+
+    loc = torch.empty((args.batch, wl.NUM_CLASSES), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        pred.run(skip_io_copy=True)
+        if world > 1:
+            # result gather over xGMI: the probabilities (0.5 MB per rank) are staged into a torch buffer by a
+            # device-to-device copy on the same stream, then all-gathered with RCCL
+            pred.copy_var_to_device("prob", loc.data_ptr(), loc.numel() * 4)
+            return sharding.all_gather_rows(loc, dist, world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-launch kernel time, live, HIP events on the launch stream (rank 0) ----
+    roof, fam_out = None, {}
+    if rank == 0:
+        reps = 5
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in body] for _ in range(reps)]
+        for r in range(reps):
+            for j, i in enumerate(body):
+                ev[r][j][0].record(stream)
+                pred.run_instruction(i)
+                ev[r][j][1].record(stream)
+        torch.cuda.synchronize(dev)
+        per_inst = {i: float(np.median([ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(reps)])) for j, i in enumerate(body)}
+        costs = layer_costs(wl, args.batch)
+        layer_names = [l[0] for l in wl.mobilenet_v1_layers()]
+        conv_idx = {}
+        for i in body:
+            if names[i].startswith("conv2d") or names[i].startswith("depthwise_conv2d"):
+                conv_idx[layer_names[len(conv_idx)]] = i
+        for key, c in costs.items():
+            ms = sum(per_inst[conv_idx[n]] for n in c["names"])
+            fam_out[key] = {"launches": len(c["names"]), "ms": round(ms, 4), "GB/s": round(c["bytes"] / ms / 1e6, 1),
+                            "TOP/s": round(c["ops"] / ms / 1e9, 2), "alg_bytes": c["bytes"], "ops": c["ops"]}
+        if args.layer_table:
+            for n in layer_names:
+                print("%-6s %8.4f ms  %s" % (n, per_inst[conv_idx[n]], names[conv_idx[n]]), file=sys.stderr)
+            other = sum(v for i, v in per_inst.items() if i not in conv_idx.values())
+            print("other (calib/pool/fc/softmax) %.4f ms" % other, file=sys.stderr)
+        dom = max(fam_out, key=lambda k: fam_out[k]["ms"])
+        d = fam_out[dom]
+        hbm_frac = d["GB/s"] / HBM_PEAK_GBS
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roof = {"kernel": dom, "bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(hbm_frac, 4), "traffic": traffic,
+                "avg_launch_ms": round(d["ms"] / d["launches"], 5), "launches_per_step": d["launches"],
+                "mfma_TOP/s": d["TOP/s"], "mfma_frac_of_dense_i8_peak": round(d["TOP/s"] / MFMA_I8_PEAK_TOPS, 4),
+                "note": "algorithmic bytes = int8 in + out + weights once per layer (SURVEY.md 8d), summed over the "
+                        "family's launches of one step, / summed launch time (HIP events on the launch stream)"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wl, W, args.cpu_seconds)
+
+    if rank == 0:
+        total_imgs = world * args.batch * args.steps
+        val = total_imgs / elapsed
+        ops_per_img = 2 * (sum(v for k, v in wl.mobilenet_v1_macs().items() if k != "act_bytes"))
+        line = {
+            "metric": "INT8 images/sec MobileNetV1 224x224", "value": round(val, 1), "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "config": {"workload": "MobileNetV1 INT8 full graph 224x224 (27 int8 convs + pool + fc + softmax), "
+                                   "random-init weights, batch %d per GPU, input resident in HBM" % args.batch,
+                       "global_batch": world * args.batch, "parallelism": "batch-split x%d, RCCL weight broadcast + logits all_gather" % world},
+            "whole_graph_TOP/s": round(val * ops_per_img / 1e12, 2),
+            "whole_graph_frac_of_i8_mfma_peak": round(val * ops_per_img / 1e12 / MFMA_I8_PEAK_TOPS, 4),
+            "roofline": roof, "kernels": fam_out, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    pred.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

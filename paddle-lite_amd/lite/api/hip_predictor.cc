@@ -1,0 +1,140 @@
+// hip_predictor.cc — see hip_predictor.h.
+#include "lite/api/hip_predictor.h"
+
+#include <cstring>
+
+namespace paddle {
+namespace lite {
+
+std::unique_ptr<KernelBase> PickKernel(const std::string& op_type, const Place& place, const std::string& alias) {
+  auto ks = KernelFactory::Global().Create(op_type, place.target, place.precision, place.layout);
+  for (auto& k : ks)
+    if (k->alias() == alias) return std::move(k);
+  LOG(FATAL) << "no kernel registered for " << op_type << "/" << alias << " at " << place.DebugString()
+             << "; registered ops:\n" << KernelFactory::Global().DebugString();
+  return nullptr;
+}
+
+Tensor* HipPredictor::Var(const std::string& name) {
+  auto it = vars_.find(name);
+  if (it == vars_.end()) it = vars_.emplace(name, std::unique_ptr<Tensor>(new Tensor)).first;
+  return it->second.get();
+}
+
+Tensor* HipPredictor::NewParam(const void* host, size_t bytes, const std::vector<int64_t>& dims, PrecisionType prec) {
+  params_.emplace_back(new Tensor);
+  Tensor* t = params_.back().get();
+  t->Resize(dims);
+  t->set_persistable(true);
+  void* p = t->mutable_data(TARGET(kHost), bytes);
+  t->set_precision(prec);
+  std::memcpy(p, host, bytes);
+  return t;
+}
+
+void HipPredictor::Emit(std::shared_ptr<OpLite> op, std::unique_ptr<KernelBase> kernel) {
+  kernel->SetContext(NewContext(TARGET(kHIP), device_));
+  op->AttachKernel(kernel.get());
+  program_.Add(Instruction(std::move(op), std::move(kernel)));
+}
+
+Tensor* HipPredictor::AddFeed(const std::string& name, const std::vector<int64_t>& dims, PrecisionType prec) {
+  Tensor* t = Var(name);
+  t->Resize(dims);
+  const size_t esz = prec == PRECISION(kInt8) ? 1 : 4;
+  t->mutable_data(TARGET(kHost), static_cast<size_t>(t->numel()) * esz);
+  t->set_precision(prec);
+  return t;
+}
+
+void HipPredictor::AddIoCopy(const std::string& in, const std::string& out, bool h2d) {
+  auto op = std::make_shared<operators::IoCopyOp>();
+  op->mutable_param().x = Var(in);
+  op->mutable_param().y = Var(out);
+  Emit(op, PickKernel("io_copy", Place(TARGET(kHIP), PRECISION(kAny), DATALAYOUT(kAny)),
+                      h2d ? "host_to_device" : "device_to_host"));
+}
+
+void HipPredictor::AddCalib(const std::string& in, const std::string& out, float scale, bool f2i) {
+  auto op = std::make_shared<operators::CalibOpLite>();
+  op->mutable_param().input = Var(in);
+  op->mutable_param().output = Var(out);
+  op->mutable_param().scale = scale;
+  Emit(op, PickKernel("calib", Place(TARGET(kHIP), PRECISION(kInt8)), f2i ? "fp32_to_int8" : "int8_to_fp32"));
+}
+
+void HipPredictor::AddConv(const std::string& op_type, const std::string& in, const std::string& out, const int8_t* w,
+                           const std::vector<int64_t>& w_dims, const float* bias, const ConvAttrs& a) {
+  auto op = std::make_shared<operators::ConvOpLite>(op_type);
+  auto& p = op->mutable_param();
+  size_t wn = 1;
+  for (auto d : w_dims) wn *= static_cast<size_t>(d);
+  p.x = Var(in);
+  p.output = Var(out);
+  p.filter = NewParam(w, wn, w_dims, PRECISION(kInt8));
+  p.bias = bias ? NewParam(bias, static_cast<size_t>(w_dims[0]) * 4, {w_dims[0]}, PRECISION(kFloat)) : nullptr;
+  p.strides = a.strides;
+  p.paddings = std::make_shared<std::vector<int>>(a.paddings);
+  p.dilations = std::make_shared<std::vector<int>>(a.dilations);
+  p.groups = a.groups;
+  p.enable_int8 = true;
+  p.input_scale = a.input_scale;
+  p.output_scale = a.output_scale;
+  p.weight_scale = a.weight_scale;
+  if (a.act != 0) {
+    p.activation_param.has_active = true;
+    p.activation_param.active_type = static_cast<lite_api::ActivationType>(a.act);
+    if (a.act == 1) p.fuse_relu = true;
+    if (a.act == 2) p.activation_param.Relu_clipped_coef = a.act_coef;
+    if (a.act == 4) p.activation_param.Leaky_relu_alpha = a.act_coef;
+  }
+  op->set_padding_algorithm(a.padding_algorithm);
+  Emit(op, PickKernel(op_type, Place(TARGET(kHIP), PRECISION(kInt8)), a.int8_out ? "int8_out" : "fp32_out"));
+}
+
+void HipPredictor::AddFc(const std::string& in, const std::string& out, const int8_t* w, int k, int n, const float* bias,
+                         float input_scale, const std::vector<float>& weight_scale, float output_scale, bool int8_out,
+                         bool relu) {
+  auto op = std::make_shared<operators::FcOpLite>();
+  auto& p = op->mutable_param();
+  p.input = Var(in);
+  p.output = Var(out);
+  p.w = NewParam(w, static_cast<size_t>(k) * n, {k, n}, PRECISION(kInt8));
+  p.bias = bias ? NewParam(bias, static_cast<size_t>(n) * 4, {n}, PRECISION(kFloat)) : nullptr;
+  p.in_num_col_dims = 1;
+  p.enable_int8 = true;
+  p.input_scale = input_scale;
+  p.weight_scale = weight_scale;
+  p.output_scale = output_scale;
+  if (relu) p.activation_type = "relu";
+  Emit(op, PickKernel("fc", Place(TARGET(kHIP), PRECISION(kInt8)), int8_out ? "int8out" : "fp32out"));
+}
+
+void HipPredictor::AddGlobalAvgPool(const std::string& in, const std::string& out) {
+  auto op = std::make_shared<operators::PoolOpLite>();
+  auto& p = op->mutable_param();
+  p.x = Var(in);
+  p.output = Var(out);
+  p.pooling_type = "avg";
+  p.global_pooling = true;
+  p.paddings = std::make_shared<std::vector<int>>(std::vector<int>{0, 0, 0, 0});
+  Emit(op, PickKernel("pool2d", Place(TARGET(kHIP), PRECISION(kFloat)), "def"));
+}
+
+void HipPredictor::AddSoftmax(const std::string& in, const std::string& out) {
+  auto op = std::make_shared<operators::SoftmaxOp>();
+  op->mutable_param().x = Var(in);
+  op->mutable_param().output = Var(out);
+  op->mutable_param().axis = -1;
+  Emit(op, PickKernel("softmax", Place(TARGET(kHIP), PRECISION(kFloat)), "def"));
+}
+
+std::vector<std::string> HipPredictor::KernelNames() {
+  std::vector<std::string> r;
+  for (auto& i : program_.instructions())
+    r.push_back(i.kernel()->name() + "/" + i.kernel()->alias() + " -> " + i.kernel()->kernel_func_name());
+  return r;
+}
+
+}  // namespace lite
+}  // namespace paddle

@@ -1,0 +1,164 @@
+// lite_capi.cc — see lite_capi.h.
+#include "lite/api/lite_capi.h"
+
+#include <cstring>
+#include <string>
+
+#include "lite/api/hip_predictor.h"
+
+using paddle::lite::HipPredictor;
+using paddle::lite::Tensor;
+
+struct pllite_predictor {
+  explicit pllite_predictor(int dev) : pred(dev) {}
+  HipPredictor pred;
+};
+
+namespace {
+thread_local std::string g_err;
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* pllite_last_error(void) { return g_err.c_str(); }
+
+int pllite_registered_kernels(const char* op_type, int precision, int layout) {
+  auto ks = paddle::lite::KernelFactory::Global().Create(op_type, TARGET(kHIP),
+                                                         static_cast<paddle::lite::PrecisionType>(precision),
+                                                         static_cast<paddle::lite::DataLayoutType>(layout));
+  return static_cast<int>(ks.size());
+}
+
+int pllite_adopt_stream(int device, void* stream) {
+  return guarded([&] { paddle::lite::TargetWrapperHip::AdoptStream(device, stream); });
+}
+
+pllite_predictor* pllite_predictor_create(int device) {
+  pllite_predictor* p = nullptr;
+  if (guarded([&] {
+        p = new pllite_predictor(device);
+        (void)paddle::lite::TargetWrapperHip::Ctx();  // fail here, loudly, when there is no gfx950 device
+      }) != 0) {
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+void pllite_predictor_destroy(pllite_predictor* p) { delete p; }
+
+int pllite_add_feed(pllite_predictor* p, const char* name, const int64_t* dims, int ndims, int precision) {
+  return guarded([&] {
+    p->pred.AddFeed(name, std::vector<int64_t>(dims, dims + ndims), static_cast<paddle::lite::PrecisionType>(precision));
+  });
+}
+int pllite_add_io_copy(pllite_predictor* p, const char* in, const char* out, int h2d) {
+  return guarded([&] { p->pred.AddIoCopy(in, out, h2d != 0); });
+}
+int pllite_add_calib(pllite_predictor* p, const char* in, const char* out, float scale, int f2i) {
+  return guarded([&] { p->pred.AddCalib(in, out, scale, f2i != 0); });
+}
+int pllite_add_conv(pllite_predictor* p, const char* op_type, const char* in, const char* out, const int8_t* w,
+                    const int64_t* w_dims, const float* bias, const int* strides, const int* paddings, int n_paddings,
+                    const int* dilations, int groups, int act, float act_coef, float input_scale,
+                    const float* weight_scale, int n_weight_scale, float output_scale, int int8_out,
+                    const char* padding_algorithm) {
+  return guarded([&] {
+    paddle::lite::ConvAttrs a;
+    a.strides = {strides[0], strides[1]};
+    a.paddings.assign(paddings, paddings + n_paddings);
+    a.dilations = {dilations[0], dilations[1]};
+    a.groups = groups;
+    a.act = act;
+    a.act_coef = act_coef;
+    a.input_scale = input_scale;
+    a.output_scale = output_scale;
+    a.weight_scale.assign(weight_scale, weight_scale + n_weight_scale);
+    a.int8_out = int8_out != 0;
+    a.padding_algorithm = padding_algorithm ? padding_algorithm : "";
+    p->pred.AddConv(op_type, in, out, w, std::vector<int64_t>(w_dims, w_dims + 4), bias, a);
+  });
+}
+int pllite_add_fc(pllite_predictor* p, const char* in, const char* out, const int8_t* w, int k, int n, const float* bias,
+                  float input_scale, const float* weight_scale, int n_ws, float output_scale, int int8_out, int relu) {
+  return guarded([&] {
+    p->pred.AddFc(in, out, w, k, n, bias, input_scale, std::vector<float>(weight_scale, weight_scale + n_ws), output_scale,
+                  int8_out != 0, relu != 0);
+  });
+}
+int pllite_add_global_avg_pool(pllite_predictor* p, const char* in, const char* out) {
+  return guarded([&] { p->pred.AddGlobalAvgPool(in, out); });
+}
+int pllite_add_softmax(pllite_predictor* p, const char* in, const char* out) {
+  return guarded([&] { p->pred.AddSoftmax(in, out); });
+}
+int pllite_set_input(pllite_predictor* p, const char* name, const void* host, int64_t bytes) {
+  return guarded([&] {
+    CHECK(p->pred.HasVar(name)) << "unknown variable " << name;
+    Tensor* t = p->pred.Var(name);
+    CHECK_EQ(static_cast<int64_t>(t->memory_size()), bytes) << "input size mismatch for " << name;
+    paddle::lite::TargetCopy(t->target(), TARGET(kHost), t->raw_data(), host, static_cast<size_t>(bytes));
+  });
+}
+int pllite_run(pllite_predictor* p, int skip_io_copy) {
+  return guarded([&] { p->pred.Run(skip_io_copy != 0); });
+}
+int pllite_num_instructions(pllite_predictor* p) { return static_cast<int>(p->pred.program().instructions().size()); }
+int pllite_run_instruction(pllite_predictor* p, int index) {
+  return guarded([&] {
+    auto& insts = p->pred.program().instructions();
+    CHECK(index >= 0 && index < static_cast<int>(insts.size())) << "instruction index out of range";
+    insts[index].Run();
+  });
+}
+int pllite_sync(pllite_predictor* p) {
+  return guarded([&] { p->pred.Sync(); });
+}
+int pllite_get_var(pllite_predictor* p, const char* name, void* host, int64_t capacity, int64_t* bytes, int64_t* dims4,
+                   int* ndims) {
+  return guarded([&] {
+    CHECK(p->pred.HasVar(name)) << "unknown variable " << name;
+    Tensor* t = p->pred.Var(name);
+    const int64_t n = static_cast<int64_t>(t->memory_size());
+    CHECK_LE(n, capacity) << "host buffer too small for " << name;
+    p->pred.Sync();
+    paddle::lite::TargetCopy(TARGET(kHost), t->target(), host, t->raw_data(), static_cast<size_t>(n));
+    if (bytes) *bytes = n;
+    if (ndims) *ndims = static_cast<int>(t->dims().size());
+    if (dims4)
+      for (size_t i = 0; i < t->dims().size() && i < 4; ++i) dims4[i] = t->dims()[static_cast<int>(i)];
+  });
+}
+void* pllite_var_device_ptr(pllite_predictor* p, const char* name) {
+  if (!p->pred.HasVar(name)) return nullptr;
+  Tensor* t = p->pred.Var(name);
+  return t->target() == TARGET(kHIP) ? t->raw_data() : nullptr;
+}
+int pllite_copy_var_to_device(pllite_predictor* p, const char* name, void* dst_dev, int64_t bytes) {
+  return guarded([&] {
+    CHECK(p->pred.HasVar(name)) << "unknown variable " << name;
+    Tensor* t = p->pred.Var(name);
+    CHECK(t->target() == TARGET(kHIP)) << name << " is not device resident";
+    CHECK_EQ(static_cast<int64_t>(t->memory_size()), bytes);
+    paddle::lite::TargetWrapperHip::MemcpyAsync(dst_dev, t->raw_data(), static_cast<size_t>(bytes), paddle::lite::IoDirection::DtoD);
+  });
+}
+int pllite_kernel_names(pllite_predictor* p, char* buf, int cap) {
+  return guarded([&] {
+    std::string s;
+    for (auto& n : p->pred.KernelNames()) s += n + "\n";
+    CHECK_LT(static_cast<int>(s.size()), cap);
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+/* lite_capi.h — a small C veneer over the C++ kernel classes (lite/kernels/hip) and the mini predictor, so that
+ * the Python test-suite and bench.py can drive the SAME objects a Paddle-Lite build would (KernelFactory lookup,
+ * SetContext / SetParam / PrepareForRun / Launch) through ctypes.  Test / bench plumbing only; the drop-in ABI of
+ * the device code is include/plhip.h.  Every function returns 0 or -1 (message in pllite_last_error()). */
+#ifndef PLLITE_CAPI_H_
+#define PLLITE_CAPI_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* pllite_last_error(void);
+/* Number of kernels registered for (op_type, kHIP, precision, layout) — registry smoke check. */
+int pllite_registered_kernels(const char* op_type, int precision, int layout);
+/* Adopt an external hipStream_t (e.g. torch's current stream) for this thread + device; call before anything else. */
+int pllite_adopt_stream(int device, void* stream);
+
+typedef struct pllite_predictor pllite_predictor;
+pllite_predictor* pllite_predictor_create(int device);
+void pllite_predictor_destroy(pllite_predictor* p);
+int pllite_add_feed(pllite_predictor* p, const char* name, const int64_t* dims, int ndims, int precision);
+int pllite_add_io_copy(pllite_predictor* p, const char* in, const char* out, int host_to_device);
+int pllite_add_calib(pllite_predictor* p, const char* in, const char* out, float scale, int fp32_to_int8);
+int pllite_add_conv(pllite_predictor* p, const char* op_type, const char* in, const char* out, const int8_t* w,
+                    const int64_t* w_dims, const float* bias, const int* strides, const int* paddings, int n_paddings,
+                    const int* dilations, int groups, int act, float act_coef, float input_scale,
+                    const float* weight_scale, int n_weight_scale, float output_scale, int int8_out,
+                    const char* padding_algorithm);
+int pllite_add_fc(pllite_predictor* p, const char* in, const char* out, const int8_t* w, int k, int n, const float* bias,
+                  float input_scale, const float* weight_scale, int n_weight_scale, float output_scale, int int8_out,
+                  int relu);
+int pllite_add_global_avg_pool(pllite_predictor* p, const char* in, const char* out);
+int pllite_add_softmax(pllite_predictor* p, const char* in, const char* out);
+int pllite_set_input(pllite_predictor* p, const char* name, const void* host, int64_t bytes);
+int pllite_run(pllite_predictor* p, int skip_io_copy);
+int pllite_sync(pllite_predictor* p);
+/* Per-instruction stepping (bench.py brackets single launches with HIP events for the roofline object). */
+int pllite_num_instructions(pllite_predictor* p);
+int pllite_run_instruction(pllite_predictor* p, int index);
+/* Copies a variable (host or device resident) to `host`; returns bytes written through *bytes. */
+int pllite_get_var(pllite_predictor* p, const char* name, void* host, int64_t capacity, int64_t* bytes,
+                   int64_t* dims4, int* ndims);
+/* Device pointer of a variable (for all_gather of logits etc.); 0 if it is not on the device. */
+void* pllite_var_device_ptr(pllite_predictor* p, const char* name);
+/* Asynchronous device-to-device copy of a device-resident variable into caller memory, on the predictor's stream. */
+int pllite_copy_var_to_device(pllite_predictor* p, const char* name, void* dst_dev, int64_t bytes);
+/* '\n'-separated "op:target/precision/layout/alias -> kernel_func_name" list of the program. */
+int pllite_kernel_names(pllite_predictor* p, char* buf, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

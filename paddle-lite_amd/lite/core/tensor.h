@@ -16,7 +16,6 @@ class DDimLite {
   using value_type = int64_t;
   DDimLite() = default;
   DDimLite(const std::vector<value_type>& x) : data_(x) {}  // NOLINT (implicit like the reference)
-  DDimLite(std::initializer_list<value_type> x) : data_(x) {}
   void ConstructFrom(const std::vector<value_type>& x) { data_ = x; }
   value_type operator[](int i) const { return data_[i]; }
   value_type& operator[](int i) { return data_[i]; }

@@ -33,7 +33,6 @@ class Type {
  private:
   Place place_;
 };
-using LiteType = Type;
 
 // type_system.h:175-189: host-like targets exchange tensors freely; anything else needs an io_copy.
 inline bool TargetCompatibleTo(TargetType a, TargetType b) {
@@ -90,3 +89,5 @@ class ParamTypeRegistry {
 
 }  // namespace lite
 }  // namespace paddle
+
+using LiteType = paddle::lite::Type;  // registration sites spell it unqualified, as in the reference

@@ -1,0 +1,76 @@
+"""Batch-split data parallelism for inference: one process per GPU, full weight replica per GPU.
+
+  * once at init: rank 0's packed int8 weights + fp32 scales/biases are broadcast (RCCL over xGMI on GPUs; gloo in
+    the CPU tests) — MobileNetV1 is ~4.3 MB, latency-bound, not on the steady-state path;
+  * per step: every rank runs images [r*B/G, (r+1)*B/G) with no collective inside the layer loop, then the
+    [B/G, 1000] fp32 probabilities are all-gathered.
+The reference has no multi-device code at all; this module is new.
+"""
+import numpy as np
+
+
+def pack_weights(W):
+    """Flatten {name: array | {field: array}} into (manifest, uint8 blob); every entry 16-byte aligned."""
+    items, blobs, off = [], [], 0
+    for name in sorted(W):
+        v = W[name]
+        fields = sorted(v.items()) if isinstance(v, dict) else [("", v)]
+        for f, arr in fields:
+            arr = np.asarray(arr)
+            shape = tuple(arr.shape)  # ascontiguousarray would promote 0-d scalars to (1,)
+            b = np.ascontiguousarray(arr).tobytes()
+            items.append((name, f, str(arr.dtype), shape, off, len(b)))
+            blobs.append(b)
+            off += len(b)
+            pad = (-off) % 16
+            blobs.append(b"\0" * pad)
+            off += pad
+    return items, np.frombuffer(b"".join(blobs), np.uint8).copy()
+
+
+def unpack_weights(items, blob):
+    W = {}
+    for name, f, dt, shape, off, n in items:
+        arr = np.frombuffer(blob[off:off + n].tobytes(), dtype=np.dtype(dt)).reshape(shape).copy()
+        if arr.shape == ():
+            arr = arr.dtype.type(arr)
+        if f == "":
+            W[name] = arr
+        else:
+            W.setdefault(name, {})[f] = arr
+    return W
+
+
+def shard_range(global_batch, rank, world):
+    """Images [lo, hi) of rank `rank`: contiguous, sizes differ by at most one (ragged batches allowed)."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_weights(W, dist, device, rank, world, src=0):
+    """Rank `src` passes its weight dict, the others None; everyone returns the same dict.
+    `dist` is torch.distributed (initialised); `device` the torch device of the transport buffer."""
+    import torch
+    if world == 1:
+        return W
+    if rank == src:
+        items, blob = pack_weights(W)
+        meta = [items, int(blob.size)]
+    else:
+        items, blob, meta = None, None, [None, None]
+    dist.broadcast_object_list(meta, src=src)
+    items, nbytes = meta
+    t = torch.from_numpy(blob).to(device) if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src)
+    return W if rank == src else unpack_weights(items, t.cpu().numpy())
+
+
+def all_gather_rows(local, dist, world):
+    """all_gather of equally sized [rows, cols] tensors into [world*rows, cols] (rank-major order)."""
+    import torch
+    if world == 1:
+        return local
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out

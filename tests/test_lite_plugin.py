@@ -1,0 +1,156 @@
+"""The C++ host side (paddle-lite_amd/lite): registry + kernel classes behind the reference's plugin interface.
+CPU part: the library loads and the kHIP kernels are registered under the reference's op names / aliases.
+GPU part: kernels driven like lite/tests/math/conv_int8_compute_test.cc:230-253 (KernelFactory -> SetContext ->
+SetParam -> PrepareForRun -> Launch) and the whole MobileNetV1-INT8 program against the oracle graph."""
+import importlib
+
+import numpy as np
+import pytest
+
+import mbv1_oracle
+
+
+@pytest.fixture(scope="module")
+def lite(pkg):
+    return importlib.import_module("paddle_lite_amd.liteapi")
+
+
+@pytest.fixture(scope="module")
+def wl(pkg):
+    return importlib.import_module("paddle_lite_amd.workloads")
+
+
+def test_registry_has_reference_kernel_set(lite):
+    L = lite.load()
+    # conv2d / depthwise_conv2d x {int8_out, fp32_out}  (conv_compute.cc:216-252), fc x {int8out, fp32out}
+    # (fc_compute.cc:368-380), calib x 2 (calib_compute.cc), io_copy x 2, pool2d, softmax
+    assert L.pllite_registered_kernels(b"conv2d", lite.PREC_INT8, lite.LAYOUT_NCHW) == 2
+    assert L.pllite_registered_kernels(b"depthwise_conv2d", lite.PREC_INT8, lite.LAYOUT_NCHW) == 2
+    assert L.pllite_registered_kernels(b"fc", lite.PREC_INT8, lite.LAYOUT_NCHW) == 2
+    assert L.pllite_registered_kernels(b"calib", lite.PREC_INT8, lite.LAYOUT_NCHW) == 2
+    assert L.pllite_registered_kernels(b"io_copy", lite.PREC_ANY, lite.LAYOUT_ANY) == 2
+    assert L.pllite_registered_kernels(b"pool2d", lite.PREC_FLOAT, lite.LAYOUT_NCHW) == 1
+    assert L.pllite_registered_kernels(b"softmax", lite.PREC_FLOAT, lite.LAYOUT_NCHW) == 1
+    assert L.pllite_registered_kernels(b"conv2d", lite.PREC_FLOAT, lite.LAYOUT_NCHW) == 0
+
+
+def test_workload_matches_survey_layer_table(wl):
+    m = wl.mobilenet_v1_macs()
+    assert m["pointwise"] == 539492352 and m["depthwise"] == 17385984 and m["first"] == 10838016
+    assert m["act_bytes"] == 10185728
+    assert len(wl.mobilenet_v1_layers()) == 27
+
+
+def test_predictor_without_gpu_raises(lite):
+    L = lite.load()
+    import ctypes
+    from paddle_lite_amd import capi
+    if capi.load().plhip_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(lite.LiteError):
+        lite.Predictor(0)
+
+
+def _single_conv(lite, plref, rng, op_type, n, cin, h, cout, k, s, pads, g, act, coef, int8_out, dil=1, algo=""):
+    x = rng.integers(-127, 128, (n, cin, h, h)).astype(np.int8)
+    w = rng.integers(-127, 128, (cout, cin // g, k, k)).astype(np.int8)
+    bias = rng.uniform(-1, 1, cout).astype(np.float32)
+    w_scale = ((1 + np.arange(cout) % 7) / 127.0 / 4.0).astype(np.float32)
+    kk = (cin // g) * k * k
+    in_scale, out_scale = 1 / 127.0, (kk / 127.0 if act != 2 else coef / 127.0)
+    p = lite.Predictor(0)
+    try:
+        p.add_feed("x", x.shape, lite.PREC_INT8)
+        p.add_io_copy("x", "xd", True)
+        p.add_conv(op_type, "xd", "yd", w, bias, (s, s), pads, (dil, dil), g, act, coef, in_scale, w_scale, out_scale, int8_out, algo)
+        p.add_io_copy("yd", "y", False)
+        p.set_input("x", x)
+        p.run()
+        p.run()  # second launch: ReInitWhenNeeded no-op path
+        y = p.get_var("y", np.int8 if int8_out else np.float32)
+        names = p.kernel_names()
+    finally:
+        p.close()
+    pads4 = pads if len(pads) == 4 else (pads[0], pads[0], pads[1], pads[1])
+    if algo == "SAME":
+        oh = (h + s - 1) // s
+        ps = max((oh - 1) * s + k - h, 0)
+        pads4 = (ps // 2, ps - ps // 2, ps // 2, ps - ps // 2)
+        dil = 1
+    sh = plref.shape(n, cin, h, h, cout, k, k, pads4, (s, s), (dil, dil), g)
+    y_ref, _ = plref.conv2d(sh, x, w, bias, in_scale, w_scale, out_scale, act, coef, int8_out)
+    return y, y_ref, names
+
+
+@pytest.mark.gpu
+def test_conv_kernel_classes_vs_oracle(lite, plref):
+    rng = np.random.default_rng(200)
+    cases = [
+        ("conv2d", 2, 16, 14, 24, 1, 1, (0, 0, 0, 0), 1, 1, 0.0),          # 1x1 -> direct MFMA GEMM
+        ("conv2d", 1, 8, 17, 5, 3, 1, (1, 2, 2, 1), 1, 2, 6.0),            # 3x3 s1 asymmetric pads, relu6
+        ("conv2d", 2, 3, 19, 33, 3, 2, (1, 1), 1, 4, 0.25),                # 3x3 s2, 2-element paddings, leaky
+        ("depthwise_conv2d", 2, 32, 15, 32, 3, 1, (1, 1, 1, 1), 32, 1, 0.0),
+        ("depthwise_conv2d", 1, 5, 33, 5, 5, 2, (2, 2, 2, 2), 5, 2, 6.0),
+        ("conv2d", 1, 8, 9, 6, 3, 1, (1, 1, 1, 1), 2, 0, 0.0),             # grouped
+    ]
+    for (op, n, cin, h, cout, k, s, pads, g, act, coef) in cases:
+        for int8_out in (True, False):
+            y, y_ref, names = _single_conv(lite, plref, rng, op, n, cin, h, cout, k, s, pads, g, act, coef, int8_out)
+            if int8_out:
+                assert np.array_equal(y, y_ref), (op, cin, cout, k, s)
+            else:
+                np.testing.assert_allclose(y, y_ref, rtol=1e-5, atol=1e-6)
+            assert any(("int8_out" if int8_out else "fp32_out") in s_ for s_ in names)
+    # padding_algorithm == "SAME" rewrites paddings in InferShape (conv_op.cc:55-81)
+    y, y_ref, _ = _single_conv(lite, plref, rng, "conv2d", 1, 4, 15, 6, 3, 2, (0, 0, 0, 0), 1, 1, 0.0, True, algo="SAME")
+    assert y.shape == y_ref.shape and np.array_equal(y, y_ref)
+
+
+@pytest.mark.gpu
+def test_bad_weight_scale_is_fatal(lite):
+    """weights scale size must equal filter number or 1 (conv_gemmlike.cc:213-215) -> LOG(FATAL)."""
+    p = lite.Predictor(0)
+    try:
+        x = np.zeros((1, 4, 8, 8), np.int8)
+        p.add_feed("x", x.shape, lite.PREC_INT8)
+        p.add_io_copy("x", "xd", True)
+        p.add_conv("conv2d", "xd", "yd", np.zeros((6, 4, 1, 1), np.int8), None, (1, 1), (0, 0, 0, 0), (1, 1), 1, 0, 0.0,
+                   1.0, np.ones(3, np.float32), 1.0, True)
+        p.set_input("x", x)
+        with pytest.raises(lite.LiteError, match="weights scale size"):
+            p.run()
+    finally:
+        p.close()
+
+
+@pytest.mark.gpu
+def test_mobilenet_v1_int8_program_vs_oracle_graph(lite, wl, plref):
+    """Whole Appendix-D program at batch 2: every int8 activation bit-exact, fp32 tail within 1e-5."""
+    W = wl.make_mobilenet_v1_weights(seed=1234)
+    rng = np.random.default_rng(201)
+    img = rng.uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+    ref = mbv1_oracle.forward(plref, wl, W, img)
+    p = lite.Predictor(0)
+    try:
+        out = wl.build_mobilenet_v1(p, W, 2)
+        p.set_input("image", img)
+        p.run()
+        names = p.kernel_names()
+        assert len(names) == 2 + 1 + 27 + 4 and sum("depthwise" in n for n in names) == 13
+        for name in ["x0", "conv1", "dw2", "pw2", "dw7", "pw7", "dw14"]:
+            got = p.get_var(name, np.int8)
+            assert np.array_equal(got, ref[name]), name
+            # synthetic scales keep the activations alive: not all-zero, not saturated
+            assert 0.02 < (got != 0).mean() and (np.abs(got.astype(np.int32)) == 127).mean() < 0.2, name
+        np.testing.assert_allclose(p.get_var("pw14", np.float32), ref["pw14"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(p.get_var("pool", np.float32), ref["pool"], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(p.get_var("pool_i8", np.int8), ref["pool_i8"])
+        np.testing.assert_allclose(p.get_var("logits", np.float32), ref["logits"], rtol=1e-5, atol=1e-5)
+        prob = p.get_var(out, np.float32)
+        np.testing.assert_allclose(prob, ref["prob"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(prob.sum(-1), 1.0, rtol=1e-5)
+        # second run with the feed already on the device (bench mode) gives the same answer
+        p.run(skip_io_copy=True)
+        assert np.array_equal(p.get_var("dw14", np.int8), ref["dw14"])
+    finally:
+        p.close()
