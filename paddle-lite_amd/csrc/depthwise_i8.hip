@@ -210,6 +210,215 @@ __global__ __launch_bounds__(256) void depthwise_i8_kernel(DwArgs a) {
   }
 }
 
+// =====================================================================================================================
+// Fast path for the MobileNet case: 3x3, dilation 1, stride 1 or 2, left pad <= 3, any H/W.
+//   * one lane = one column quad (4 consecutive outputs) x a vertical strip of RS output rows;
+//   * every input row of the strip is fetched with ONE unaligned global load per lane (8 B for stride 1, 12 B for
+//     stride 2) that already contains all taps of the 4 outputs; all (RS*S + 2) row loads are issued before any use,
+//     so each lane keeps 10-15 loads in flight (this op is HBM-bound; bytes in flight are what matters);
+//   * the 4 sliding windows are cut with v_alignbyte_b32 and hit the packed filter row with v_dot4_i32_i8; each input
+//     row's windows are reused for the (up to) 3 output rows it feeds;
+//   * no LDS, no barrier, no shuffles; image borders are handled by per-lane byte masks (zero padding).
+template <int ACT>
+__device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, float b2, float alpha, float lo2, float hi2) {
+  if (ACT == ACT_RELU || ACT == ACT_RELU6) {
+    uint32_t t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)a[j], s2, b2), lo2, hi2);
+    const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
+    return ((p + 0x01010101u) >> 1) & 0x7f7f7f7fu;
+  }
+  int q[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float y2 = __fmaf_rn((float)a[j], s2, b2);
+    if (ACT == ACT_LEAKY) y2 = y2 > 0.f ? y2 : alpha * y2;
+    const int t = (int)__builtin_amdgcn_fmed3f(y2, lo2, hi2);
+    q[j] = (t + 1 + (t >> 31)) >> 1;
+  }
+  return pack4_i8(q[0], q[1], q[2], q[3]);
+}
+
+template <int OUT, int ACT>
+__device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int room, const int (&acc)[4], float s, float bi) {
+  if (OUT == OUT_I32) {
+    int* yp = reinterpret_cast<int*>(a.y) + off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < room) yp[j] = acc[j];
+  } else if (OUT == OUT_F32) {
+    float* yp = reinterpret_cast<float*>(a.y) + off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f = __fmaf_rn((float)acc[j], s, bi);
+      if (ACT == ACT_RELU) f = fmaxf(f, 0.f);
+      if (ACT == ACT_RELU6) f = fminf(fmaxf(f, 0.f), a.alpha);
+      if (ACT == ACT_LEAKY) f = f > 0.f ? f : a.alpha * f;
+      if (j < room) yp[j] = f;
+    }
+  } else {
+    const float hi2 = ACT == ACT_RELU6 ? fminf(a.alpha + a.alpha, 254.f) : 254.f;
+    const float lo2 = (ACT == ACT_RELU || ACT == ACT_RELU6) ? 0.f : -254.f;
+    const uint32_t pk = dw_requant4<ACT>(acc, s + s, bi + bi, a.alpha, lo2, hi2);
+    int8_t* yp = reinterpret_cast<int8_t*>(a.y) + off;
+    if (room >= 4) {
+      __builtin_memcpy(yp, &pk, 4);  // may be unaligned when OW % 4 != 0: fine for global memory
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < room) yp[j] = (int8_t)((pk >> (8 * j)) & 0xff);
+    }
+  }
+}
+
+template <int OUT, int S, int RS>
+__global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
+  constexpr int NIN = (RS - 1) * S + 3;  // input rows per strip
+  constexpr int ND = S == 1 ? 2 : 3;     // dwords per row load
+  const int owq = (a.ow + 3) >> 2;
+  const int spp = (a.oh + RS - 1) / RS;  // strips per plane
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)a.planes * spp * owq;
+  if (gid >= total) return;
+  const int xq = (int)(gid % owq);
+  const long strip = gid / owq;
+  const int sidx = (int)(strip % spp);
+  const long plane = strip / spp;
+  const int ch = (int)(plane % a.C);
+  const int oy0 = sidx * RS;
+  const int iy0 = oy0 * S - a.pt;
+  const int start = 4 * xq * S - a.pl;       // input column of byte 0 of the row window
+  const int sh = start < 0 ? -start : 0;     // bytes of left padding inside the window (only xq == 0)
+  const int lcol = start + sh;               // first column actually loaded
+  const long plane_base = plane * (long)a.h * a.w;
+  const long tensor_bytes = (long)a.planes * a.h * a.w;
+
+  // per-lane validity mask of the ND*4 window bytes (after the left-pad shift): byte i <-> column start + i
+  uint32_t cmask[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = start + 4 * d + i;
+      if (col >= 0 && col < a.w) m |= 0xffu << (8 * i);
+    }
+    cmask[d] = m;
+  }
+
+  // ---- issue every row load of the strip ----
+  uint32_t in[NIN][ND];
+#pragma unroll
+  for (int t = 0; t < NIN; ++t) {
+    const int ih = iy0 + t;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) in[t][d] = 0;
+    if (ih >= 0 && ih < a.h && lcol < a.w) {
+      const long gofs = plane_base + (long)ih * a.w + lcol;
+      const int8_t* src = a.x + gofs;
+      if (gofs + 4 * ND <= tensor_bytes) {
+        __builtin_memcpy(&in[t][0], src, 4 * ND);
+      } else {  // the very last bytes of the tensor: never read past the end
+        for (int i = 0; i < 4 * ND; ++i)
+          if (gofs + i < tensor_bytes) in[t][i >> 2] |= (uint32_t)(uint8_t)src[i] << (8 * (i & 3));
+      }
+    }
+  }
+  // filter rows packed (w0, w1, w2, 0), scale, bias
+  uint32_t wr[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int8_t* wp = a.wt + (size_t)ch * 9 + r * 3;
+    wr[r] = (uint32_t)(uint8_t)wp[0] | ((uint32_t)(uint8_t)wp[1] << 8) | ((uint32_t)(uint8_t)wp[2] << 16);
+  }
+  const float sc = a.scale ? a.scale[ch] : 1.f;
+  const float bi = a.bias ? a.bias[ch] : 0.f;
+
+  int acc[RS][4];
+#pragma unroll
+  for (int o = 0; o < RS; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[o][j] = 0;
+
+#pragma unroll
+  for (int t = 0; t < NIN; ++t) {
+    uint32_t d[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] = in[t][i];
+    if (sh) {  // left border lane: make room for the zero padding bytes
+      const int s8 = 8 * sh;
+      if (ND == 3) d[2] = (d[2] << s8) | (d[1] >> (32 - s8));
+      d[1] = (d[1] << s8) | (d[0] >> (32 - s8));
+      d[0] = d[0] << s8;
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] &= cmask[i];
+    uint32_t win[4];
+    if (S == 1) {
+      win[0] = d[0];
+      win[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 1);
+      win[2] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
+      win[3] = __builtin_amdgcn_alignbyte(d[1], d[0], 3);
+    } else {
+      win[0] = d[0];
+      win[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
+      win[2] = d[1];
+      win[3] = __builtin_amdgcn_alignbyte(d[ND - 1], d[1], 2);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      if ((t - r) % S != 0) continue;
+      const int o = (t - r) / S;
+      if (t - r < 0 || o >= RS) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[o][j] = __builtin_amdgcn_sdot4((int)win[j], (int)wr[r], acc[o][j], false);
+    }
+  }
+
+  const size_t obase = ((size_t)plane * a.oh + oy0) * a.ow + 4 * xq;
+  const int room = a.ow - 4 * xq;
+#define DW_ROWS(ACTV)                                                                              \
+  _Pragma("unroll") for (int o = 0; o < RS; ++o) {                                                 \
+    if (oy0 + o < a.oh) dw_finish_row<OUT, ACTV>(a, obase + (size_t)o * a.ow, room, acc[o], sc, bi); \
+  }
+  if (OUT == OUT_I32) {
+    DW_ROWS(ACT_NONE)
+  } else {
+    switch (a.act) {
+      case ACT_RELU: DW_ROWS(ACT_RELU) break;
+      case ACT_RELU6: DW_ROWS(ACT_RELU6) break;
+      case ACT_LEAKY: DW_ROWS(ACT_LEAKY) break;
+      default: DW_ROWS(ACT_NONE) break;
+    }
+  }
+#undef DW_ROWS
+}
+
+template <int OUT, int S>
+static void launch_dw_direct_s(const DwArgs& a, int rs, hipStream_t s) {
+  const long owq = (a.ow + 3) >> 2;
+  const long spp = (a.oh + rs - 1) / rs;
+  const long total = (long)a.planes * spp * owq;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (rs == 8) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 8>), dim3(blocks), dim3(256), 0, s, a);
+  else if (rs == 7) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 7>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 4>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+static bool launch_dw_direct(const DwArgs& a, int out, hipStream_t s) {
+  if (!(a.kh == 3 && a.kw == 3 && a.dh == 1 && a.dw == 1 && a.sh == a.sw && (a.sw == 1 || a.sw == 2) && a.pl <= 3)) return false;
+  if ((long)a.planes * a.h * a.w >= (1L << 31) || (long)a.planes * a.oh * a.ow >= (1L << 31)) return false;
+  // rows per strip: amortise the 2-row halo while keeping many lanes (and bytes) in flight
+  int rs;
+  if (a.sw == 1) rs = (a.oh % 8 == 0) ? 8 : (a.oh % 7 == 0 ? 7 : (a.oh >= 8 ? 8 : (a.oh >= 5 ? 7 : 4)));
+  else rs = (a.oh % 7 == 0 && a.oh <= 14) ? 7 : 4;
+  const bool s1 = a.sw == 1;
+  if (out == OUT_I32) s1 ? launch_dw_direct_s<OUT_I32, 1>(a, rs, s) : launch_dw_direct_s<OUT_I32, 2>(a, rs, s);
+  else if (out == OUT_F32) s1 ? launch_dw_direct_s<OUT_F32, 1>(a, rs, s) : launch_dw_direct_s<OUT_F32, 2>(a, rs, s);
+  else s1 ? launch_dw_direct_s<OUT_I8, 1>(a, rs, s) : launch_dw_direct_s<OUT_I8, 2>(a, rs, s);
+  return true;
+}
+
 template <int OUT>
 static void launch_dw_t(const DwArgs& a, int fast, unsigned blocks, size_t lds, hipStream_t s) {
   switch (fast) {
@@ -222,6 +431,7 @@ static void launch_dw_t(const DwArgs& a, int fast, unsigned blocks, size_t lds, 
 }
 
 int launch_depthwise(const DwArgs& a, int out, hipStream_t s) {
+  if (launch_dw_direct(a, out, s)) return 0;
   int fast = 0;
   if (a.kh == a.kw && (a.kw == 3 || a.kw == 5) && a.sh == a.sw && (a.sw == 1 || a.sw == 2) && a.dh == 1 && a.dw == 1)
     fast = a.kw * 10 + a.sw;

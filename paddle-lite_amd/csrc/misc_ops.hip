@@ -76,6 +76,57 @@ __global__ __launch_bounds__(256) void fc_i8_kernel(const int8_t* __restrict__ x
   }
 }
 
+// Fast path (k % 4 == 0, x 4-byte aligned): a 256-thread block owns 64 output columns x FCF_MB rows; its 4 waves split
+// the k-quads, x dwords are wave-uniform (scalar loads feeding v_dot4_i32_i8), partial sums meet in LDS.
+#define FCF_MB 16
+template <int OUT>
+__global__ __launch_bounds__(256) void fc_i8_fast_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ wp,
+                                                         const float* __restrict__ scale, const float* __restrict__ bias,
+                                                         void* __restrict__ y, int m, int k, int n, int relu) {
+  __shared__ int red[4][FCF_MB][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = blockIdx.x * 64 + lane;
+  const int m0 = blockIdx.y * FCF_MB;
+  const int k4n = k >> 2;
+  const int q0 = (k4n * wave) / 4, q1 = (k4n * (wave + 1)) / 4;
+  const int colc = col < n ? col : n - 1;
+  const uint32_t* wq = reinterpret_cast<const uint32_t*>(wp) + colc;
+  const uint32_t* xq = reinterpret_cast<const uint32_t*>(x);
+  int acc[FCF_MB];
+#pragma unroll
+  for (int i = 0; i < FCF_MB; ++i) acc[i] = 0;
+  for (int kq = q0; kq < q1; ++kq) {
+    const int wv = (int)wq[(size_t)kq * n];
+#pragma unroll
+    for (int i = 0; i < FCF_MB; ++i) {
+      const int mi = m0 + i < m ? m0 + i : m - 1;  // wave-uniform
+      const int xv = (int)xq[(size_t)mi * k4n + kq];
+      acc[i] = __builtin_amdgcn_sdot4(xv, wv, acc[i], false);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FCF_MB; ++i) red[wave][i][lane] = acc[i];
+  __syncthreads();
+  if (col >= n) return;
+  const float s = (OUT == OUT_I32) ? 1.f : scale[col];
+  const float bi = (OUT != OUT_I32 && bias) ? bias[col] : 0.f;
+#pragma unroll
+  for (int j = 0; j < FCF_MB / 4; ++j) {
+    const int i = wave * (FCF_MB / 4) + j;
+    if (m0 + i >= m) break;
+    const int a = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
+    const size_t off = (size_t)(m0 + i) * n + col;
+    if (OUT == OUT_I32) {
+      reinterpret_cast<int*>(y)[off] = a;
+    } else {
+      const float f = epilogue_f32(a, s, bi, relu ? ACT_RELU : ACT_NONE, 0.f);
+      if (OUT == OUT_F32) reinterpret_cast<float*>(y)[off] = f;
+      else reinterpret_cast<int8_t*>(y)[off] = (int8_t)round_sat_i8(f);
+    }
+  }
+}
+
 // q = clamp(round_half_away(x * (1.f/scale)), -127, 127)   type_trans.cc:45,183-184
 __global__ void calib_f32_to_i8_kernel(const float* __restrict__ x, int8_t* __restrict__ y, float inv_scale, int64_t count, int vec) {
   const int64_t nq = vec ? count >> 2 : 0;
@@ -152,6 +203,13 @@ void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s)
 
 void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const float* bias, void* y, int m, int k, int n,
                int relu, int out, hipStream_t s) {
+  if ((k & 3) == 0 && ((uintptr_t)x & 3) == 0) {
+    dim3 grid((n + 63) / 64, (m + FCF_MB - 1) / FCF_MB);
+    if (out == OUT_I32) hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_I32>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
+    else if (out == OUT_F32) hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_F32>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
+    else hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_I8>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
+    return;
+  }
   dim3 grid((n + 255) / 256, (m + FC_MB - 1) / FC_MB);
   if (out == OUT_I32) hipLaunchKernelGGL((fc_i8_kernel<OUT_I32>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
   else if (out == OUT_F32) hipLaunchKernelGGL((fc_i8_kernel<OUT_F32>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);

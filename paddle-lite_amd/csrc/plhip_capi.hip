@@ -234,7 +234,8 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
   if (out != PLHIP_OUT_I32_ACC && !scale) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: scale required");
   if (d->act != PLHIP_ACT_NONE && d->act != PLHIP_ACT_RELU && d->act != PLHIP_ACT_RELU6 && d->act != PLHIP_ACT_LEAKY_RELU)
     return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_int8: unsupported activation");
-  if ((size_t)d->n * g.Np >= ((size_t)1 << 31) - 256 || (size_t)d->cin * d->h * d->w >= ((size_t)1 << 31))
+  if ((size_t)d->n * g.Np >= ((size_t)1 << 31) - 256 || (size_t)d->cin * d->h * d->w >= ((size_t)1 << 31) ||
+      (size_t)d->cout * g.N >= ((size_t)1 << 31))
     return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_int8: tensor too large for 32-bit column index");
 
   const bool direct = g.is_1x1_s1_p0 && (g.N & 3) == 0 && aligned(x, 4);
