@@ -37,12 +37,29 @@ __device__ __forceinline__ void load_a(const int8_t* __restrict__ wp, int mt, in
   }
 }
 
-__device__ __forceinline__ void load_b(const int8_t* __restrict__ xb, int ks, int h, int K, int HWX, uint32_t (&raw)[16]) {
+// ALIGNED: every row dword is 4-byte aligned and inside the tensor.  Otherwise (dense slabs with HW % 4 != 0, e.g. the
+// 7x7 layers, or a misaligned base) the dwords are read unaligned — legal for global memory on gfx950 — and the one
+// dword that would cross the end of the tensor is assembled bytewise.  Columns >= HW of a 4-column group then hold
+// bytes of the next row: harmless, a GEMM column only ever feeds its own (discarded) output column.
+template <bool ALIGNED>
+__device__ __forceinline__ void load_b(const int8_t* __restrict__ xb, int ks, int h, int K, int XP, long room, uint32_t (&raw)[16]) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     int k = ks * 32 + 16 * h + j;
     k = k < K ? k : K - 1;  // rows >= K meet zero-padded weights; only the address must stay legal
-    raw[j] = *reinterpret_cast<const uint32_t*>(xb + (size_t)k * HWX);
+    const long off = (long)k * XP;
+    if (ALIGNED) {
+      raw[j] = *reinterpret_cast<const uint32_t*>(xb + off);
+    } else if (off + 4 <= room) {
+      uint32_t v;
+      __builtin_memcpy(&v, xb + off, 4);
+      raw[j] = v;
+    } else {
+      uint32_t v = 0;
+      for (int i = 0; i < 4; ++i)
+        if (off + i < room) v |= (uint32_t)(uint8_t)xb[off + i] << (8 * i);
+      raw[j] = v;
+    }
   }
 }
 
@@ -162,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
   }
 }
 
-template <int MA, int OUT, bool VEC_STORE, bool MFULL>
+template <int MA, int OUT, bool VEC_STORE, bool MFULL, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler too
@@ -179,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   const int b = n4 / g.HWX;
   const int hw = n4 - b * g.HWX;
   const int8_t* xb = g.x + (size_t)b * g.x_bstride + hw;
+  const long room = g.x_bytes - ((long)b * (long)g.x_bstride + hw);  // bytes from xb to the end of the tensor
 
   v16i acc[MA][4];
 #pragma unroll
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
 
   uint32_t raw[16];
   v4i af[MA];
-  load_b(xb, 0, h, g.K, g.HWX, raw);
+  load_b<ALIGNED>(xb, 0, h, g.K, g.XP, room, raw);
   load_a<MA>(g.wp, mt, g.KS, 0, lane, af);
 
   for (int ks = 0; ks < g.KS; ++ks) {
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
 #pragma unroll
     for (int a = 0; a < MA; ++a) ac[a] = af[a];
     if (ks + 1 < g.KS) {  // prefetch the next K-step under this step's MFMAs
-      load_b(xb, ks + 1, h, g.K, g.HWX, raw);
+      load_b<ALIGNED>(xb, ks + 1, h, g.K, g.XP, room, raw);
       load_a<MA>(g.wp, mt, g.KS, ks + 1, lane, af);
     }
 #pragma unroll
@@ -287,27 +305,30 @@ __global__ void im2col_i8_kernel(Im2colArgs a) {
 
 // ---- host-side launchers (called from plhip_capi.hip) ----
 template <int MA, int OUT>
-static void launch_gemm_t(const GemmArgs& g, bool vec_store, hipStream_t s) {
+static void launch_gemm_t(const GemmArgs& g, bool vec_store, bool aligned, hipStream_t s) {
   const long waves = (long)g.MT * g.NT;
   const unsigned blocks = (unsigned)((waves + 3) / 4);
   const bool mfull = g.M % (32 * MA) == 0;
-  if (vec_store && mfull)
-    hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, true, true>), dim3(blocks), dim3(256), 0, s, g);
+  if (!aligned)
+    hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, false, false, false>), dim3(blocks), dim3(256), 0, s, g);
+  else if (vec_store && mfull)
+    hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, true, true, true>), dim3(blocks), dim3(256), 0, s, g);
   else if (vec_store)
-    hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, true, false>), dim3(blocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, true, false, true>), dim3(blocks), dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, false, false>), dim3(blocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, false, false, true>), dim3(blocks), dim3(256), 0, s, g);
 }
 
-void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, hipStream_t s) {
+void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s) {
+  if (!aligned_loads) vec_store = false;
   if (ma == 1) {
-    if (out == OUT_I32) launch_gemm_t<1, OUT_I32>(g, vec_store, s);
-    else if (out == OUT_F32) launch_gemm_t<1, OUT_F32>(g, vec_store, s);
-    else launch_gemm_t<1, OUT_I8>(g, vec_store, s);
+    if (out == OUT_I32) launch_gemm_t<1, OUT_I32>(g, vec_store, aligned_loads, s);
+    else if (out == OUT_F32) launch_gemm_t<1, OUT_F32>(g, vec_store, aligned_loads, s);
+    else launch_gemm_t<1, OUT_I8>(g, vec_store, aligned_loads, s);
   } else {
-    if (out == OUT_I32) launch_gemm_t<2, OUT_I32>(g, vec_store, s);
-    else if (out == OUT_F32) launch_gemm_t<2, OUT_F32>(g, vec_store, s);
-    else launch_gemm_t<2, OUT_I8>(g, vec_store, s);
+    if (out == OUT_I32) launch_gemm_t<2, OUT_I32>(g, vec_store, aligned_loads, s);
+    else if (out == OUT_F32) launch_gemm_t<2, OUT_F32>(g, vec_store, aligned_loads, s);
+    else launch_gemm_t<2, OUT_I8>(g, vec_store, aligned_loads, s);
   }
 }
 

@@ -96,7 +96,20 @@ __global__ __launch_bounds__(256) void fc_i8_fast_kernel(const int8_t* __restric
   int acc[FCF_MB];
 #pragma unroll
   for (int i = 0; i < FCF_MB; ++i) acc[i] = 0;
-  for (int kq = q0; kq < q1; ++kq) {
+  int kq = q0;
+  for (; kq + 4 <= q1; kq += 4) {  // 4 k-quads per round: 4 vector loads of w, one 16-byte scalar load of x per row
+    int wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wv[u] = (int)wq[(size_t)(kq + u) * n];
+#pragma unroll
+    for (int i = 0; i < FCF_MB; ++i) {
+      const int mi = m0 + i < m ? m0 + i : m - 1;  // wave-uniform
+      const uint32_t* xr = xq + (size_t)mi * k4n + kq;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[i] = __builtin_amdgcn_sdot4((int)xr[u], wv[u], acc[i], false);
+    }
+  }
+  for (; kq < q1; ++kq) {
     const int wv = (int)wq[(size_t)kq * n];
 #pragma unroll
     for (int i = 0; i < FCF_MB; ++i) {
@@ -157,17 +170,18 @@ __global__ void calib_i8_to_f32_kernel(const int8_t* __restrict__ x, float* __re
     y[t] = scale * (float)x[t];
 }
 
-// one wave per (n, c) plane
+// 16 lanes per (n, c) plane, 16 planes per 256-thread block
 __global__ __launch_bounds__(256) void global_avg_pool_kernel(const float* __restrict__ x, int nc, int spatial, float* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
-  const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (plane >= nc) return;
-  const float* p = x + (size_t)plane * spatial;
+  const int sub = threadIdx.x & 15;
+  const int plane = blockIdx.x * 16 + (threadIdx.x >> 4);
   float s = 0.f;
-  for (int i = lane; i < spatial; i += 64) s += p[i];
+  if (plane < nc) {
+    const float* p = x + (size_t)plane * spatial;
+    for (int i = sub; i < spatial; i += 16) s += p[i];
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) y[plane] = s / (float)spatial;
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+  if (sub == 0 && plane < nc) y[plane] = s / (float)spatial;
 }
 
 // one block per row
@@ -235,7 +249,7 @@ void launch_calib_i8_to_f32(const int8_t* x, float* y, float scale, int64_t coun
 }
 
 void launch_global_avg_pool(const float* x, int nc, int spatial, float* y, hipStream_t s) {
-  hipLaunchKernelGGL(global_avg_pool_kernel, dim3((nc + 3) / 4), dim3(256), 0, s, x, nc, spatial, y);
+  hipLaunchKernelGGL(global_avg_pool_kernel, dim3((nc + 15) / 16), dim3(256), 0, s, x, nc, spatial, y);
 }
 
 void launch_softmax(const float* x, int rows, int cols, float* y, hipStream_t s) {

@@ -44,9 +44,12 @@ plhip_status fail(plhip_ctx* c, plhip_status st, const char* fmt, const char* a 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
+enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2 };
+
 struct ConvGeom {
   int oh, ow, G, Mg, Cg, Kg, N, Np, MA, MT, MT32, KS;
   bool is_1x1_s1_p0;
+  ConvImpl impl;  // a pure function of the descriptor, so that pack and run agree
 };
 
 bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
@@ -75,6 +78,13 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   g->KS = cdiv(g->Kg, 32);
   g->is_1x1_s1_p0 = d->kh == 1 && d->kw == 1 && d->stride[0] == 1 && d->stride[1] == 1 && d->pad[0] == 0 &&
                     d->pad[1] == 0 && d->pad[2] == 0 && d->pad[3] == 0;
+  // impl selection (the analogue of conv_compute.cc:87-134): 1x1 -> GEMM straight on the NCHW slab; small-Cin 3x3 s2
+  // stem -> direct (reference: DirectConv / conv3x3s2_direct_int8.cc); everything else im2col + GEMM (GemmLikeConv)
+  if (g->is_1x1_s1_p0) g->impl = IMPL_GEMM_1X1;
+  else if (plhip::conv3x3s2_direct_supported(d->cin, d->cout, d->kh, d->kw, d->stride[0], d->stride[1], d->dil[0], d->dil[1],
+                                             d->groups, d->pad[2]))
+    g->impl = IMPL_DIRECT_3X3S2;
+  else g->impl = IMPL_IM2COL_GEMM;
   return true;
 }
 
@@ -197,6 +207,7 @@ plhip_status plhip_event_destroy(plhip_ctx* ctx, void* event) {
 size_t plhip_conv_packed_weight_bytes(const plhip_conv_desc* d) {
   ConvGeom g;
   if (!conv_geom(d, &g)) return 0;
+  if (g.impl == IMPL_DIRECT_3X3S2) return plhip::conv3x3s2_direct_packed_bytes(d->cin, d->cout);
   return (size_t)g.G * g.MT32 * g.KS * 1024;
 }
 
@@ -204,7 +215,12 @@ plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d, c
   ConvGeom g;
   if (!ctx || !w_oihw || !w_packed) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pack_conv_weights: null argument");
   if (!conv_geom(d, &g)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pack_conv_weights: bad conv descriptor");
-  plhip::launch_pack_weights(w_oihw, (int8_t*)w_packed, g.G, g.Mg, g.Kg, g.MT32, g.KS, ctx->stream);
+  if (g.impl == IMPL_DIRECT_3X3S2) {
+    if (!aligned(w_packed, 4)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pack_conv_weights: packed buffer must be 4-byte aligned");
+    plhip::launch_pack_conv3x3s2_direct(w_oihw, (uint32_t*)w_packed, d->cin, d->cout, ctx->stream);
+  } else {
+    plhip::launch_pack_weights(w_oihw, (int8_t*)w_packed, g.G, g.Mg, g.Kg, g.MT32, g.KS, ctx->stream);
+  }
   LAUNCHCHK(ctx, "pack_weights");
   return PLHIP_OK;
 }
@@ -212,14 +228,15 @@ plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d, c
 size_t plhip_conv_workspace_bytes(const plhip_conv_desc* d) {
   ConvGeom g;
   if (!conv_geom(d, &g)) return 0;
-  if (g.is_1x1_s1_p0 && (g.N & 3) == 0) return 0;
+  if (g.impl != IMPL_IM2COL_GEMM) return 0;
   return (size_t)d->n * g.G * g.Kg * g.Np;
 }
 
 const char* plhip_conv_impl_name(const plhip_conv_desc* d) {
   ConvGeom g;
   if (!conv_geom(d, &g)) return "invalid";
-  if (g.is_1x1_s1_p0 && (g.N & 3) == 0) return "conv1x1s1_gemm_int8_mfma32x32x32";
+  if (g.impl == IMPL_GEMM_1X1) return "conv1x1s1_gemm_int8_mfma32x32x32";
+  if (g.impl == IMPL_DIRECT_3X3S2) return "conv_3x3s2_direct_int8_dot4";
   return "conv_im2col_gemm_int8_mfma32x32x32";
 }
 
@@ -238,10 +255,25 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
       (size_t)d->cout * g.N >= ((size_t)1 << 31))
     return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_int8: tensor too large for 32-bit column index");
 
-  const bool direct = g.is_1x1_s1_p0 && (g.N & 3) == 0 && aligned(x, 4);
+  if (g.impl == IMPL_DIRECT_3X3S2) {
+    plhip::DirectS2Args a;
+    a.x = x;
+    a.wp = (const uint32_t*)w_packed;
+    a.y = y;
+    a.scale = scale;
+    a.bias = bias;
+    a.n = d->n; a.cin = d->cin; a.h = d->h; a.w = d->w; a.cout = d->cout; a.coutp = rup(d->cout, 4);
+    a.oh = g.oh; a.ow = g.ow; a.pt = d->pad[0]; a.pl = d->pad[2]; a.act = d->act; a.alpha = d->act_alpha;
+    plhip::launch_conv3x3s2_direct(a, (int)out, ctx->stream);
+    LAUNCHCHK(ctx, "conv3x3s2_direct");
+    return PLHIP_OK;
+  }
+  const bool direct = g.impl == IMPL_GEMM_1X1;
   const int8_t* bmat = x;
   size_t x_bstride = (size_t)d->cin * g.N, x_gstride = (size_t)g.Cg * g.N;
-  int hwx = g.N;
+  int hwx = g.Np, xp = g.N;
+  long x_bytes = (long)d->n * d->cin * g.N;
+  bool aligned_loads = (g.N & 3) == 0 && aligned(x, 4);
   if (!direct) {
     const size_t need = (size_t)d->n * g.G * g.Kg * g.Np;
     if (!workspace || workspace_bytes < need || !aligned(workspace, 4))
@@ -273,7 +305,9 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     bmat = (const int8_t*)workspace;
     x_bstride = (size_t)g.G * g.Kg * g.Np;
     x_gstride = (size_t)g.Kg * g.Np;
-    hwx = g.Np;
+    xp = g.Np;
+    x_bytes = (long)need;
+    aligned_loads = true;
   }
   const size_t esz = out == PLHIP_OUT_I8 ? 1 : 4;
   const bool vec_store = hwx == g.N && aligned(y, 4 * esz);
@@ -289,6 +323,8 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     a.KS = g.KS;
     a.HWX = hwx;
     a.HWY = g.N;
+    a.XP = xp;
+    a.x_bytes = x_bytes - (long)grp * (long)x_gstride;
     a.NB = d->n;
     a.x_bstride = x_bstride;
     a.y_bstride = (size_t)d->cout * g.N;
@@ -296,7 +332,7 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     a.NT = cdiv(d->n * hwx, 128);
     a.act = d->act;
     a.alpha = d->act_alpha;
-    plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store, ctx->stream);
+    plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store, aligned_loads, ctx->stream);
     LAUNCHCHK(ctx, "gemm_i8");
   }
   return PLHIP_OK;

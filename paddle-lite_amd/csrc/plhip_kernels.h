@@ -13,7 +13,9 @@ struct GemmArgs {
   const float* scale;  // [M] folded per-channel scale (unused for I32)
   const float* bias;   // [M] folded bias or nullptr
   int M, K, KS;        // rows, reduction length, K-steps of 32
-  int HWX, HWY;        // columns per image in x (pitch, multiple of 4) / valid columns per image in y
+  int HWX, HWY;        // columns per image in n-space (multiple of 4) / valid columns per image in y (= y row pitch)
+  int XP;              // x row pitch in bytes (HWX for the im2col buffer, HW for a dense NCHW slab)
+  long x_bytes;        // bytes readable from x (guards the last partial dword when XP % 4 != 0)
   int NB;              // images
   size_t x_bstride, y_bstride;
   int MT, NT;          // wave tiles along M (32*MA rows) and N (128 columns)
@@ -45,10 +47,26 @@ struct DwArgs {
   float alpha;
 };
 
-void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, hipStream_t s);
+void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);
 void launch_pack_weights(const int8_t* w, int8_t* wp, int G, int Mg, int Kg, int MT32, int KS, hipStream_t s);
 void launch_im2col(const Im2colArgs& a, hipStream_t s);
 int launch_depthwise(const DwArgs& a, int out, hipStream_t s);  // returns 0 or -3 (unsupported LDS size)
+
+// direct 3x3 stride-2 convolution for small Cin (network stems)
+struct DirectS2Args {
+  const int8_t* x;
+  const uint32_t* wp;  // packed [cin*3 + r][coutp] dwords (w0, w1, w2, 0)
+  void* y;
+  const float* scale;
+  const float* bias;
+  int n, cin, h, w, cout, coutp, oh, ow, pt, pl;
+  int act;
+  float alpha;
+};
+bool conv3x3s2_direct_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int pl);
+size_t conv3x3s2_direct_packed_bytes(int cin, int cout);
+void launch_pack_conv3x3s2_direct(const int8_t* w_oihw, uint32_t* wp, int cin, int cout, hipStream_t s);
+void launch_conv3x3s2_direct(const DirectS2Args& a, int out, hipStream_t s);
 
 void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s);
 void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const float* bias, void* y, int m, int k, int n,

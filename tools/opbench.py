@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Per-op micro-benchmark through the C ABI (device-resident buffers, HIP events on the ctx stream).
+Usage: python tools/opbench.py [pw|dw|conv1|all] [--batch 128] [--reps 30]
+Prints one line per MobileNetV1 layer: time, algorithmic GB/s, TOP/s."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.import_package()
+capi = pkg.capi
+import importlib  # noqa: E402
+
+wl = importlib.import_module("paddle_lite_amd.workloads")
+
+
+def time_op(ctx, fn, reps):
+    L = ctx.L
+    for _ in range(3):
+        fn()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.plhip_event_create(ctx.h, C.byref(e0))
+    L.plhip_event_create(ctx.h, C.byref(e1))
+    L.plhip_event_record(ctx.h, e0)
+    for _ in range(reps):
+        fn()
+    L.plhip_event_record(ctx.h, e1)
+    ms = C.c_float()
+    ctx.check(L.plhip_event_elapsed_ms(ctx.h, e0, e1, C.byref(ms)), "elapsed")
+    return ms.value / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--f32", action="store_true", help="fp32 output instead of int8")
+    args = ap.parse_args()
+    rng = np.random.default_rng(0)
+    B = args.batch
+    tot = 0.0
+    with capi.Context(0) as ctx:
+        L = ctx.L
+        for (name, op, cin, cout, k, s, p, g, hin) in wl.mobilenet_v1_layers():
+            kind = "conv1" if name == "conv1" else ("dw" if g > 1 else "pw")
+            if args.what not in ("all", kind, name):
+                continue
+            ho = (hin + 2 * p - k) // s + 1
+            d = capi.conv_desc(B, cin, hin, hin, cout, k, k, (p, p, p, p), (s, s), (1, 1), g, capi.ACT_RELU, 0.0)
+            x = rng.integers(-127, 128, (B, cin, hin, hin), dtype=np.int8)
+            w = rng.integers(-127, 128, (cout, cin // g, k, k), dtype=np.int8)
+            dx, dw = ctx.to_device(x), ctx.to_device(w)
+            ds = ctx.to_device(np.full(cout, 1e-4, np.float32))
+            db = ctx.to_device(np.zeros(cout, np.float32))
+            out_kind = capi.OUT_F32 if (args.f32 or name == "pw14") else capi.OUT_I8
+            esz = 4 if out_kind == capi.OUT_F32 else 1
+            dy = ctx.malloc(B * cout * ho * ho * esz)
+            if g > 1:
+                fn = lambda: ctx.check(L.plhip_depthwise_conv_int8(ctx.h, C.byref(d), dx, dw, ds, db, dy, out_kind), "dw")
+            else:
+                dwp = ctx.malloc(L.plhip_conv_packed_weight_bytes(C.byref(d)))
+                ctx.check(L.plhip_pack_conv_weights(ctx.h, C.byref(d), dw, dwp), "pack")
+                wsb = L.plhip_conv_workspace_bytes(C.byref(d))
+                dws = ctx.malloc(wsb) if wsb else C.c_void_p()
+                fn = lambda: ctx.check(L.plhip_conv2d_int8(ctx.h, C.byref(d), dx, dwp, ds, db, dy, out_kind, dws, wsb), "conv")
+            ms = time_op(ctx, fn, args.reps)
+            macs = B * ho * ho * cout * (cin // g) * k * k
+            byts = B * (cin * hin * hin + cout * ho * ho * esz) + w.size
+            tot += ms
+            print("%-6s %-4s %4d->%4d %3dx%-3d s%d  %8.2f us  %7.1f GB/s  %7.1f TOP/s  %s" % (
+                name, kind, cin, cout, hin, hin, s, ms * 1e3, byts / ms / 1e6, 2 * macs / ms / 1e9,
+                L.plhip_conv_impl_name(C.byref(d)).decode() if g == 1 else "depthwise"), flush=True)
+            for q in list(ctx._allocs):
+                ctx.free(q)
+    print("total %.2f us" % (tot * 1e3))
+
+
+if __name__ == "__main__":
+    main()
