@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer timing table to stderr")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="predictors per GPU, each on its own host thread + HIP stream with batch/streams images "
+                         "(the reference's one-predictor-per-thread model, cxx_api.h:103-137); kernels of different "
+                         "streams overlap, hiding per-launch fill/drain")
     return ap.parse_args()
 
 
@@ -82,7 +86,7 @@ def cpu_baseline(wl, W, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or done >= 256:
             break
-    return {"value": round(done / el, 2), "unit": "img/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+    return {"value": round(done / el, 2), "unit": "img/s", "cores": int(os.environ["OMP_NUM_THREADS"]),
             "kind": "port",
             "sample": "%d images of the same MobileNetV1-INT8 graph, batch 1 each, %.1f s; oracle/plref.c restatement of the "
                       "reference's im2col+GEMM int8 path (its ARM NEON kernels cannot run on x86; its x86 backend has no "
@@ -91,6 +95,8 @@ def cpu_baseline(wl, W, seconds):
 
 def main():
     args = parse()
+    # the CPU baseline's OpenMP team = the cores this process may actually use (not every core of the host)
+    os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0))))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
@@ -116,37 +122,103 @@ def main():
     W = wl.make_mobilenet_v1_weights(seed=1234) if rank == 0 else None
     W = sharding.broadcast_weights(W, dist, dev, rank, world)
 
-    stream = torch.cuda.current_stream(dev)
-    pred = lite.Predictor(local_rank, stream=stream.cuda_stream)
-    out_name = wl.build_mobilenet_v1(pred, W, args.batch)
+    import threading
+    S = max(1, args.streams)
+    assert args.batch % S == 0, "--batch must be divisible by --streams"
+    sub = args.batch // S
+    main_stream = torch.cuda.current_stream(dev)
+    streams = [main_stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    preds = [None] * S
     rng = np.random.default_rng(1000 + rank)
-    pred.set_input("image", rng.uniform(-1, 1, (args.batch, 3, 224, 224)).astype(np.float32))
-    pred.run(skip_io_copy=False)  # first run: uploads the feed, PrepareForRun (weight pack, scale fold) everywhere
+    images = [rng.uniform(-1, 1, (sub, 3, 224, 224)).astype(np.float32) for _ in range(S)]
+
+    p_bytes = sub * wl.NUM_CLASSES * 4
+    loc = torch.empty((args.batch, wl.NUM_CLASSES), dtype=torch.float32, device=dev) if world > 1 else None
+
+    class Worker(threading.Thread):
+        """One predictor, one host thread, one HIP stream (TargetWrapperHip state is per thread)."""
+
+        def __init__(self, i):
+            super().__init__(daemon=True)
+            self.i, self.cmd, self.done, self.err = i, threading.Semaphore(0), threading.Semaphore(0), None
+            self.step_done = threading.Semaphore(0)
+            self.events = []
+            self.n = 0
+            self.alive = True
+
+        def run(self):
+            try:
+                torch.cuda.set_device(local_rank)
+                p = lite.Predictor(local_rank, stream=streams[self.i].cuda_stream)
+                wl.build_mobilenet_v1(p, W, sub)
+                p.set_input("image", images[self.i])
+                p.run(skip_io_copy=False)  # uploads the feed; PrepareForRun (weight pack, scale fold) everywhere
+                p.sync()
+                preds[self.i] = p
+            except Exception as e:  # noqa: BLE001
+                self.err = e
+            self.done.release()
+            while True:
+                self.cmd.acquire()
+                if not self.alive:
+                    break
+                try:
+                    for s_ in range(self.n):
+                        preds[self.i].run(skip_io_copy=True)
+                        if world > 1:  # stage this shard's probabilities for the all_gather of step s_
+                            preds[self.i].copy_var_to_device("prob", loc.data_ptr() + self.i * p_bytes, p_bytes)
+                            self.events[s_].record(streams[self.i])
+                            self.step_done.release()
+                except Exception as e:  # noqa: BLE001
+                    self.err = e
+                self.done.release()
+
+    workers = [Worker(i) for i in range(1, S)]
+    for w_ in workers:
+        w_.start()
+    pred = lite.Predictor(local_rank, stream=main_stream.cuda_stream)
+    out_name = wl.build_mobilenet_v1(pred, W, sub)
+    pred.set_input("image", images[0])
+    pred.run(skip_io_copy=False)
     pred.sync()
+    preds[0] = pred
+    for w_ in workers:
+        w_.done.acquire()
+        if w_.err:
+            raise w_.err
     n_inst = pred.num_instructions()
     names = pred.kernel_names()
     io_idx = [i for i, n in enumerate(names) if n.startswith("io_copy")]
     body = [i for i in range(n_inst) if i not in io_idx]
 
-    loc = torch.empty((args.batch, wl.NUM_CLASSES), dtype=torch.float32, device=dev) if world > 1 else None
+    def run_steps(n):
+        """n steps on every stream of this GPU; the other predictors run on their own host threads."""
+        for w_ in workers:
+            w_.n = n
+            w_.events = [torch.cuda.Event() for _ in range(n)] if world > 1 else []
+            w_.cmd.release()
+        for s_ in range(n):
+            pred.run(skip_io_copy=True)
+            if world > 1:
+                # result gather over xGMI: every predictor stages its [sub, 1000] probabilities into one torch buffer
+                # (device-to-device, on its own stream); the main stream waits for them and all-gathers with RCCL
+                pred.copy_var_to_device("prob", loc.data_ptr(), p_bytes)
+                for w_ in workers:
+                    w_.step_done.acquire()
+                    main_stream.wait_event(w_.events[s_])
+                sharding.all_gather_rows(loc, dist, world)
+        for w_ in workers:
+            w_.done.acquire()
+            if w_.err:
+                raise w_.err
 
-    def step():
-        pred.run(skip_io_copy=True)
-        if world > 1:
-            # result gather over xGMI: the probabilities (0.5 MB per rank) are staged into a torch buffer by a
-            # device-to-device copy on the same stream, then all-gathered with RCCL
-            pred.copy_var_to_device("prob", loc.data_ptr(), loc.numel() * 4)
-            return sharding.all_gather_rows(loc, dist, world)
-
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -156,6 +228,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    stream = main_stream
 
     # ---- per-launch kernel time, live, HIP events on the launch stream (rank 0) ----
     roof, fam_out = None, {}
@@ -169,7 +242,7 @@ def main():
                 ev[r][j][1].record(stream)
         torch.cuda.synchronize(dev)
         per_inst = {i: float(np.median([ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(reps)])) for j, i in enumerate(body)}
-        costs = layer_costs(wl, args.batch)
+        costs = layer_costs(wl, sub)
         layer_names = [l[0] for l in wl.mobilenet_v1_layers()]
         conv_idx = {}
         for i in body:
@@ -203,7 +276,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(wl, W, args.cpu_seconds)
+        cpu = cpu_baseline(wl, W, args.cpu_seconds)  # OMP_NUM_THREADS was pinned to the usable cores in main()
 
     if rank == 0:
         total_imgs = world * args.batch * args.steps
@@ -215,13 +288,16 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "MobileNetV1 INT8 full graph 224x224 (27 int8 convs + pool + fc + softmax), "
-                                   "random-init weights, batch %d per GPU, input resident in HBM" % args.batch,
+                                   "random-init weights, batch %d per GPU (%d predictor thread(s)/stream(s) x %d), input resident in HBM" % (args.batch, S, sub),
                        "global_batch": world * args.batch, "parallelism": "batch-split x%d, RCCL weight broadcast + logits all_gather" % world},
             "whole_graph_TOP/s": round(val * ops_per_img / 1e12, 2),
             "whole_graph_frac_of_i8_mfma_peak": round(val * ops_per_img / 1e12 / MFMA_I8_PEAK_TOPS, 4),
             "roofline": roof, "kernels": fam_out, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    for w_ in workers:
+        w_.alive = False
+        w_.cmd.release()
     pred.close()
     if world > 1:
         dist.destroy_process_group()

@@ -23,6 +23,8 @@
 //     stored as one dword per row (32 lanes x 4 B = 128 contiguous bytes of an NCHW row);
 //   * no LDS and no barrier in this first version: tiles are private to the wave.
 // The MFMA's k-slot <-> (lane>>5, byte) map never matters: A and B use the same one.
+#include <stdlib.h>
+
 #include "plhip_device.h"
 #include "plhip_kernels.h"
 
@@ -79,7 +81,8 @@ __device__ __forceinline__ float act2(float y2, float alpha) {  // activation on
 }
 
 template <int MA, int OUT, bool VEC_STORE, bool MFULL, int ACT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&acc)[MA][4], int mt, int h, int b, int hw) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&acc)[MA][4], int mt, int h, int b, int hw,
+                                              const float* lsb) {
   const int hwy_room = g.HWY - hw;  // columns hw+i with i < hwy_room are real outputs (im2col pitch pad)
   const size_t ybase = (size_t)b * g.y_bstride + hw;
   const float hi2 = ACT == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
@@ -91,19 +94,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
     for (int gq = 0; gq < 4; ++gq) {
       const int m0 = mbase + 8 * gq + 4 * h;
       if (!MFULL && m0 >= g.M) continue;
+      // scale / bias come from LDS (staged at kernel start): a global load here would sit behind the previous rows'
+      // stores in the in-order vmcnt queue and serialise the epilogue into one memory round trip per row group
       v4f sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
       if (OUT != OUT_I32) {
-        if (MFULL || m0 + 4 <= g.M) {
-          __builtin_memcpy(&sc, g.scale + m0, 16);
-          if (g.bias) __builtin_memcpy(&bi, g.bias + m0, 16);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (m0 + e < g.M) {
-              sc[e] = g.scale[m0 + e];
-              if (g.bias) bi[e] = g.bias[m0 + e];
-            }
-        }
+        sc = *reinterpret_cast<const v4f*>(lsb + a * 32 + 8 * gq + 4 * h);
+        bi = *reinterpret_cast<const v4f*>(lsb + MA * 32 + a * 32 + 8 * gq + 4 * h);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -179,6 +175,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
   }
 }
 
+// Stage this wave's MA*32 folded scales and biases into LDS: lsb[0 .. MA*32) scales, lsb[MA*32 .. 2*MA*32) biases.
+template <int MA>
+__device__ __forceinline__ void stage_scale_bias(const GemmArgs& g, int mt, int lane, float* lsb) {
+#pragma unroll
+  for (int t = 0; t < (MA * 32 + 63) / 64; ++t) {
+    const int j = t * 64 + lane;
+    if (j < MA * 32) {
+      const int m = mt * MA * 32 + j;
+      lsb[j] = (g.scale && m < g.M) ? g.scale[m] : 1.f;
+      lsb[MA * 32 + j] = (g.bias && m < g.M) ? g.bias[m] : 0.f;
+    }
+  }
+}
+
 template <int MA, int OUT, bool VEC_STORE, bool MFULL, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
@@ -187,6 +197,9 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   if (wid >= (long)g.MT * g.NT) return;  // wave-uniform; the kernel uses no barrier
   const int mt = (int)(wid % g.MT);
   const int nt = (int)(wid / g.MT);
+  __shared__ __attribute__((aligned(16))) float lsb_all[4][2 * MA * 32];
+  float* lsb = lsb_all[wave];
+  if (OUT != OUT_I32) stage_scale_bias<MA>(g, mt, lane, lsb);
   const int c = lane & 31, h = lane >> 5;
   const int ntot = g.NB * g.HWX;  // multiple of 4 by construction
 
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   load_b<ALIGNED>(xb, 0, h, g.K, g.XP, room, raw);
   load_a<MA>(g.wp, mt, g.KS, 0, lane, af);
 
-  for (int ks = 0; ks < g.KS; ++ks) {
+  for (int ks = 0; ks < ((g.dbg & 2) ? 0 : g.KS); ++ks) {
     v4i bf[4];
 #pragma unroll
     for (int jg = 0; jg < 4; ++jg) {
@@ -236,16 +249,295 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
         acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[a], bf[i], acc[a][i], 0, 0, 0);
   }
 
-  if (!nvalid) return;
+  if (!nvalid || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
-    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw);
+    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
     return;
   }
   switch (g.act) {  // wave-uniform: one straight-line epilogue per activation
-    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw); break;
-    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw); break;
-    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw); break;
-    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw); break;
+    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb); break;
+    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb); break;
+  }
+}
+
+// =====================================================================================================================
+// LDS-shared variant for M >= 128: a 256-thread block owns a (4 * 32*MA) x 128 tile; its 4 waves split M and SHARE the
+// B tile.  Per stage (4 K-steps = 128 k) wave w fetches + transposes K-step w of the stage (16 coalesced dword loads,
+// 32 v_perm) and writes its four 1-KiB MFMA fragments to LDS in fragment order (ds_write_b128, conflict free); after
+// ONE barrier per stage every wave reads all 16 fragments back (ds_read_b128, lane-linear) for its own 4*MA MFMAs per
+// K-step.  B therefore crosses L2 -> CU once per block instead of once per wave (4x less), LDS is double buffered
+// (2 x 16 KiB) and the next stage's global loads are in flight under the current stage's MFMAs.  A fragments stay
+// private (fragment-ordered, one coalesced 1-KiB load each) and are prefetched two K-steps ahead in a 4-deep
+// register ring with static indices.
+template <int MA, int OUT, bool VEC_STORE, bool MFULL, bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) v4i bs[2][4][4][64];  // [buf][kstep][i][lane] : 32 KiB
+  __shared__ __attribute__((aligned(16))) float lsb_all[4][2 * MA * 32];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mtb_n = (g.MT + 3) >> 2;  // blocks along M
+  const int mtb = blockIdx.x % mtb_n;
+  const int nt = blockIdx.x / mtb_n;
+  const int mt = mtb * 4 + wave;
+  const bool mactive = mt < g.MT;  // wave-uniform; inactive waves still load their share of B and hit the barriers
+  const int mtc = mactive ? mt : g.MT - 1;
+  float* lsb = lsb_all[wave];
+  if (OUT != OUT_I32) stage_scale_bias<MA>(g, mtc, lane, lsb);
+  const int c = lane & 31, h = lane >> 5;
+  const int ntot = g.NB * g.HWX;
+
+  int n4 = nt * 128 + 4 * c;
+  const bool nvalid = n4 < ntot;
+  if (!nvalid) n4 = 0;
+  const int b = n4 / g.HWX;
+  const int hw = n4 - b * g.HWX;
+  const int8_t* xb = g.x + (size_t)b * g.x_bstride + hw;
+  const long room = g.x_bytes - ((long)b * (long)g.x_bstride + hw);
+
+  v16i acc[MA][4];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][i][r] = 0;
+
+  const int KS = g.KS;
+  const int S = (KS + 3) >> 2;
+  uint32_t raw[16];
+  v4i a0[MA], a1[MA], a2[MA], a3[MA];
+
+  auto stage_write = [&](int buf) {  // transpose raw (this wave's K-step) into 4 fragments of bs[buf][wave]
+    v4i bf[4];
+#pragma unroll
+    for (int jg = 0; jg < 4; ++jg) {
+      uint32_t o0, o1, o2, o3;
+      transpose4x4_b8(raw[4 * jg], raw[4 * jg + 1], raw[4 * jg + 2], raw[4 * jg + 3], o0, o1, o2, o3);
+      bf[0][jg] = (int)o0;
+      bf[1][jg] = (int)o1;
+      bf[2][jg] = (int)o2;
+      bf[3][jg] = (int)o3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bs[buf][wave][i][lane] = bf[i];
+  };
+  auto kstep = [&](int buf, int kk, const v4i (&af)[MA]) {
+    v4i bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bf[i] = bs[buf][kk][i][lane];
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[a], bf[i], acc[a][i], 0, 0, 0);
+  };
+  auto load_a_c = [&](int ks, v4i (&af)[MA]) {  // clamped: K-steps past the end reload the last one (never used)
+    load_a<MA>(g.wp, mtc, KS, ks < KS ? ks : KS - 1, lane, af);
+  };
+
+  // prologue: stage 0 into LDS, A ring primed with K-steps 0 and 1
+  if (wave < KS) load_b<ALIGNED>(xb, wave, h, g.K, g.XP, room, raw);
+  load_a_c(0, a0);
+  load_a_c(1, a1);
+  if (wave < KS) stage_write(0);
+  __syncthreads();
+
+  for (int s = 0; s < ((g.dbg & 2) ? 0 : S); ++s) {
+    const int buf = s & 1;
+    const int ks0 = 4 * s;
+    const bool more = s + 1 < S;
+    const int myks = ks0 + 4 + wave;  // the K-step this wave stages for the next round
+    if (more && myks < KS) load_b<ALIGNED>(xb, myks, h, g.K, g.XP, room, raw);
+    // 4 K-steps, A ring: slot kk holds K-step ks0+kk; refill two steps ahead
+    load_a_c(ks0 + 2, a2);
+    if (mactive) kstep(buf, 0, a0);
+    load_a_c(ks0 + 3, a3);
+    if (mactive && ks0 + 1 < KS) kstep(buf, 1, a1);
+    load_a_c(ks0 + 4, a0);
+    if (mactive && ks0 + 2 < KS) kstep(buf, 2, a2);
+    load_a_c(ks0 + 5, a1);
+    if (mactive && ks0 + 3 < KS) kstep(buf, 3, a3);
+    if (more && myks < KS) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (!nvalid || !mactive || (g.dbg & 1)) return;
+  if (OUT == OUT_I32) {
+    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
+    return;
+  }
+  switch (g.act) {
+    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb); break;
+    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb); break;
+  }
+}
+
+// =====================================================================================================================
+// LDS-DMA ring variant (the fast path for MFMA-heavy layers: M >= 256-ish, K >= 128, 4-byte aligned rows).
+// PMC on the register-staged kernel showed MFMA busy ~13 % per wave and one full memory latency per stage: register
+// staging cannot keep enough K-steps in flight (VGPR-bound), and the in-order vmcnt couples the short A loads to the
+// long B loads.  Here NOTHING in the K loop loads into VGPRs from global memory:
+//   * per K-step the block needs a raw B slab (32 k-rows x 128 columns = 4 KiB, NCHW rows as they lie in memory) and
+//     each wave its own MA fragment-ordered A tiles (1 KiB each).  Both are fetched by LDS-DMA
+//     (global_load_lds dword / dwordx4): asynchronous, no VGPRs, D-1 K-steps in flight per wave in an NS-slot ring;
+//   * a wave waits with a COUNTED s_waitcnt vmcnt for its own share of K-step ks, one raw s_barrier makes the whole
+//     slot visible, then every wave reads the raw rows (16 ds_read_b32), transposes them in registers (32 v_perm) and
+//     reads its A tiles (ds_read_b128) for 4*MA MFMAs.  The transposes are redundant across the 4 waves but run on the
+//     VALU beside the MFMA pipe (128 of 256 MFMA cycles per K-step at MA = 2).
+// One barrier per K-step; slot reuse distance NS - (D-1) = 2 iterations, so a slot is rewritten only after every wave
+// has passed the barrier that follows its last read.
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// GD_D = K-steps in flight (including the one being consumed); ring slots GD_NS = GD_D + 1.
+template <int MA, int OUT, bool VEC_STORE, bool MFULL, int GD_D>
+__global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(GemmArgs g) {
+  constexpr int GD_NS = GD_D + 1;
+  constexpr int SLOT = 4096 + 4 * MA * 1024;
+  constexpr int PER = 4 + MA;  // DMA instructions per wave per K-step
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // GD_NS * SLOT ring + 4 waves x scale/bias (ONE LDS object)
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mtb_n = (g.MT + 3) >> 2;
+  const int mtb = blockIdx.x % mtb_n;
+  const int nt = blockIdx.x / mtb_n;
+  const int mt = mtb * 4 + wave;
+  const bool mactive = mt < g.MT;
+  const int mtc = mactive ? mt : g.MT - 1;
+  const int c = lane & 31, h = lane >> 5;
+  const int ntot = g.NB * g.HWX;
+
+  int n4 = nt * 128 + 4 * c;
+  const bool nvalid = n4 < ntot;
+  if (!nvalid) n4 = 0;
+  const int b = n4 / g.HWX;
+  const int hw = n4 - b * g.HWX;
+  const int8_t* xb = g.x + (size_t)b * g.x_bstride + hw;
+  const int8_t* ab = g.wp + (size_t)mtc * MA * g.KS * 1024 + lane * 16;
+  const int KS = g.KS;
+  float* lsb = reinterpret_cast<float*>(ring + GD_NS * SLOT) + wave * 2 * MA * 32;
+
+  auto issue = [&](int ks, int slot) {
+    uint8_t* sb = ring + slot * SLOT;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 8 * wave + 2 * q;  // rows row, row+1 of the K-step: lanes 0-31 / 32-63
+      int k = ks * 32 + row + h;
+      k = k < g.K ? k : g.K - 1;
+      __builtin_amdgcn_global_load_lds((glb_ptr)(xb + (size_t)k * g.XP), (lds_ptr)(sb + row * 128), 4, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(ab + ((size_t)a * KS + ks) * 1024), (lds_ptr)(sb + 4096 + (wave * MA + a) * 1024), 16, 0, 0);
+  };
+
+  v16i acc[MA][4];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][i][r] = 0;
+
+  // prologue: D-1 K-steps in flight
+#pragma unroll
+  for (int p = 0; p < GD_D - 1; ++p)
+    if (p < KS) issue(p, p);
+  // scale / bias -> LDS behind the prologue DMA (their wait then coincides with the first K-step's)
+  if (OUT != OUT_I32) stage_scale_bias<MA>(g, mtc, lane, lsb);
+
+  // Software pipeline inside the wave: while the MFMAs of K-step ks run on the matrix pipe, the raw rows of K-step
+  // ks+1 are read from LDS and transposed on the VALU (independent instruction streams the scheduler interleaves).
+  auto wait_landed = [&](int younger) {  // my DMA share of a K-step has landed once <= `younger` later K-steps are pending
+    switch (younger) {                   // wave-uniform
+      case 0: wait_vmcnt<0>(); break;
+      case 1: wait_vmcnt<1 * PER>(); break;
+      case 2: wait_vmcnt<2 * PER>(); break;
+      case 3: wait_vmcnt<(GD_D > 3 ? 3 : 2) * PER>(); break;
+      case 4: wait_vmcnt<(GD_D > 4 ? 4 : 2) * PER>(); break;
+      case 5: wait_vmcnt<(GD_D > 5 ? 5 : 2) * PER>(); break;
+      default: wait_vmcnt<(GD_D > 6 ? 6 : 2) * PER>(); break;
+    }
+  };
+  auto read_slot = [&](int slot, uint32_t (&raw)[16], v4i (&af)[MA]) {
+    const uint8_t* sb = ring + slot * SLOT;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) raw[j] = *reinterpret_cast<const uint32_t*>(sb + (16 * h + j) * 128 + 4 * c);
+#pragma unroll
+    for (int a = 0; a < MA; ++a) af[a] = *reinterpret_cast<const v4i*>(sb + 4096 + (wave * MA + a) * 1024 + lane * 16);
+  };
+  auto transpose = [&](const uint32_t (&raw)[16], v4i (&bf)[4]) {
+#pragma unroll
+    for (int jg = 0; jg < 4; ++jg) {
+      uint32_t o0, o1, o2, o3;
+      transpose4x4_b8(raw[4 * jg], raw[4 * jg + 1], raw[4 * jg + 2], raw[4 * jg + 3], o0, o1, o2, o3);
+      bf[0][jg] = (int)o0;
+      bf[1][jg] = (int)o1;
+      bf[2][jg] = (int)o2;
+      bf[3][jg] = (int)o3;
+    }
+  };
+
+  uint32_t raw[16];
+  v4i af_cur[MA], af_nxt[MA], bf_cur[4], bf_nxt[4];
+  {  // K-step 0 into registers
+    const int pend = KS - 1 < GD_D - 2 ? KS - 1 : GD_D - 2;
+    wait_landed(pend < 0 ? 0 : pend);
+    __builtin_amdgcn_s_barrier();
+    read_slot(0, raw, af_cur);
+    transpose(raw, bf_cur);
+  }
+  int slot_nxt = 1, islot = GD_D - 1;
+  const int kend = (g.dbg & 2) ? 0 : KS;
+  for (int ks = 0; ks < kend; ++ks) {
+    if (ks + GD_D - 1 < KS) issue(ks + GD_D - 1, islot);
+    islot = islot + 1 == GD_NS ? 0 : islot + 1;
+    const bool has_next = ks + 1 < KS;
+    if (has_next) {
+      // K-steps ks+2 .. min(ks+D-1, KS-1) of mine may still be in flight
+      const int last = ks + GD_D - 1 < KS - 1 ? ks + GD_D - 1 : KS - 1;
+      wait_landed(last - (ks + 1));
+      __builtin_amdgcn_s_barrier();  // slot ks+1 complete for everyone; slot ks-1 (refilled next) no longer read by anyone
+      read_slot(slot_nxt, raw, af_nxt);
+      slot_nxt = slot_nxt + 1 == GD_NS ? 0 : slot_nxt + 1;
+    }
+    // One basic block: 4*MA MFMAs of K-step ks and the 32 v_perm of K-step ks+1, interleaved by the scheduler hints
+    // below (an in-order wave cannot reach VALU work placed behind a queue of MFMAs).  Waves without rows (M tail)
+    // run the MFMAs on clamped tiles and never store; on the last K-step the transposes work on stale registers.
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur[a], bf_cur[i], acc[a][i], 0, 0, 0);
+    transpose(raw, bf_nxt);
+#pragma unroll
+    for (int q = 0; q < 4 * MA; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 32 / (4 * MA), 0);  // its share of the VALU transposes
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bf_cur[i] = bf_nxt[i];
+#pragma unroll
+    for (int a = 0; a < MA; ++a) af_cur[a] = af_nxt[a];
+  }
+
+  if (!nvalid || !mactive || (g.dbg & 1)) return;
+  if (OUT == OUT_I32) {
+    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
+    return;
+  }
+  switch (g.act) {
+    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb); break;
+    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb); break;
   }
 }
 
@@ -304,11 +596,58 @@ __global__ void im2col_i8_kernel(Im2colArgs a) {
 }
 
 // ---- host-side launchers (called from plhip_capi.hip) ----
+static int gemm_variant() {  // PLHIP_GEMM_VARIANT: 0 auto, 1 private-tile kernel, 2 register-staged LDS kernel, 3 LDS-DMA ring
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PLHIP_GEMM_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 template <int MA, int OUT>
 static void launch_gemm_t(const GemmArgs& g, bool vec_store, bool aligned, hipStream_t s) {
+  const bool mfull = g.M % (32 * MA) == 0;
+  const int var = gemm_variant();
+  const bool use_dma = aligned && (var == 3 || var == 4 || (var == 0 && g.MT >= 4 && g.KS >= 4));
+  if (use_dma) {
+    const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)g.NT);
+    const bool deep = var == 4;
+    const int depth = deep ? 8 : 4;
+    const size_t lds = (size_t)(depth + 1) * (4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4;
+#define PLHIP_LAUNCH_DMA(VS, MF, DD)                                                                              \
+  do {                                                                                                            \
+    auto kfn = gemm_i8_dma_kernel<MA, OUT, VS, MF, DD>;                                                           \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, s, g);                                                  \
+  } while (0)
+    if (deep) {
+      if (vec_store && mfull) PLHIP_LAUNCH_DMA(true, true, 8);
+      else if (vec_store) PLHIP_LAUNCH_DMA(true, false, 8);
+      else PLHIP_LAUNCH_DMA(false, false, 8);
+    } else {
+      if (vec_store && mfull) PLHIP_LAUNCH_DMA(true, true, 4);
+      else if (vec_store) PLHIP_LAUNCH_DMA(true, false, 4);
+      else PLHIP_LAUNCH_DMA(false, false, 4);
+    }
+#undef PLHIP_LAUNCH_DMA
+    return;
+  }
+  const bool use_lds = var == 2 || (var == 0 && g.MT >= 2 && g.KS >= 2);
+  if (use_lds) {
+    const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)g.NT);
+    if (!aligned)
+      hipLaunchKernelGGL((gemm_i8_lds_kernel<MA, OUT, false, false, false>), dim3(blocks), dim3(256), 0, s, g);
+    else if (vec_store && mfull)
+      hipLaunchKernelGGL((gemm_i8_lds_kernel<MA, OUT, true, true, true>), dim3(blocks), dim3(256), 0, s, g);
+    else if (vec_store)
+      hipLaunchKernelGGL((gemm_i8_lds_kernel<MA, OUT, true, false, true>), dim3(blocks), dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL((gemm_i8_lds_kernel<MA, OUT, false, false, true>), dim3(blocks), dim3(256), 0, s, g);
+    return;
+  }
   const long waves = (long)g.MT * g.NT;
   const unsigned blocks = (unsigned)((waves + 3) / 4);
-  const bool mfull = g.M % (32 * MA) == 0;
   if (!aligned)
     hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, false, false, false>), dim3(blocks), dim3(256), 0, s, g);
   else if (vec_store && mfull)
@@ -319,8 +658,24 @@ static void launch_gemm_t(const GemmArgs& g, bool vec_store, bool aligned, hipSt
     hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, false, false, true>), dim3(blocks), dim3(256), 0, s, g);
 }
 
-void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s) {
+void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s) {
   if (!aligned_loads) vec_store = false;
+  // The packed layout is a sequence of 32-row fragment tiles, so a layer packed for MA = 2 can also run with MA = 1
+  // (32-row wave tiles): do so for M <= 128, where 64-row tiles would leave waves of the 4-wave block without work.
+  static int ma_env = -1;
+  if (ma_env < 0) {
+    const char* e = getenv("PLHIP_GEMM_MA");
+    ma_env = e ? atoi(e) : 0;
+  }
+  GemmArgs g = g_in;
+  static int dbg_env = -1;
+  if (dbg_env < 0) {
+    const char* e = getenv("PLHIP_GEMM_DEBUG");
+    dbg_env = e ? atoi(e) : 0;
+  }
+  g.dbg = dbg_env;
+  if (ma == 2 && ((ma_env == 0 && g.M <= 128 && g.M > 64) || ma_env == 1)) ma = 1;
+  g.MT = (g.M + 32 * ma - 1) / (32 * ma);
   if (ma == 1) {
     if (out == OUT_I32) launch_gemm_t<1, OUT_I32>(g, vec_store, aligned_loads, s);
     else if (out == OUT_F32) launch_gemm_t<1, OUT_F32>(g, vec_store, aligned_loads, s);

@@ -21,6 +21,7 @@ struct GemmArgs {
   int MT, NT;          // wave tiles along M (32*MA rows) and N (128 columns)
   int act;
   float alpha;
+  int dbg;             // PLHIP_GEMM_DEBUG (timing experiments only): 1 = skip the epilogue, 2 = skip the K loop
 };
 
 struct Im2colArgs {
