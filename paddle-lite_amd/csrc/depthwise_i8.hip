@@ -14,6 +14,8 @@
 //   * results leave as one dword (4 x int8) or one 16-B vector (fp32 / int32) per lane, coalesced along W.
 // Fast paths: 3x3 and 5x5, stride 1 and 2, dilation 1, any padding.  Everything else (other k, dilation)
 // takes a scalar LDS-byte path in the same kernel.
+#include <stdlib.h>
+
 #include "plhip_device.h"
 #include "plhip_kernels.h"
 
@@ -271,27 +273,83 @@ __device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int r
   }
 }
 
-template <int OUT, int S, int RS>
-__global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
+// Row fetch, branch free: the row index is clamped (an out-of-image row only zeroes the masks), the column start is
+// clamped for the left border (the missing bytes are shifted in as zeros), and — only in the TAIL instantiation, which
+// the last workgroup alone runs — the address is pulled back so that the load never crosses the end of the tensor.
+template <int ND, bool TAIL>
+__device__ __forceinline__ void dw_load_row(const int8_t* __restrict__ xplane, int ih, int h, int w, int lcol, int sh,
+                                            long plane_room, const uint32_t (&cmask)[ND], uint32_t (&d)[ND]) {
+  const bool rv = ih >= 0 && ih < h;
+  const int ihc = ih < 0 ? 0 : (ih >= h ? h - 1 : ih);
+  int off = ihc * w + lcol;  // byte offset inside the plane
+  int back = 0;
+  if (TAIL) {
+    const long lim = plane_room - 4 * ND;  // last offset from which 4*ND bytes are still inside the tensor
+    if (off > lim) {
+      back = off - (int)(lim < 0 ? 0 : lim);
+      off -= back;
+    }
+  }
+  __builtin_memcpy(d, xplane + off, 4 * ND);
+  if (TAIL && back) {  // bytes were fetched `back` too early: shift them down, zeros come in from the top
+    const int s8 = 8 * (back & 3), dw = back >> 2;
+    uint32_t t[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const uint32_t lo = (i + dw < ND) ? d[(i + dw < ND) ? i + dw : 0] : 0u;
+      const uint32_t hi = (i + dw + 1 < ND) ? d[(i + dw + 1 < ND) ? i + dw + 1 : 0] : 0u;
+      t[i] = s8 ? ((lo >> s8) | (hi << (32 - s8))) : lo;
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] = t[i];
+  }
+  if (sh) {  // left border lane: make room for the zero padding bytes
+    const int s8 = 8 * sh;
+    if (ND == 3) d[ND - 1] = (d[ND - 1] << s8) | (d[ND - 2] >> (32 - s8));
+    d[1] = (d[1] << s8) | (d[0] >> (32 - s8));
+    d[0] = d[0] << s8;
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) d[i] = rv ? (d[i] & cmask[i]) : 0u;
+}
+
+// STAGE (int8 output, narrow planes): PMC showed the 14x14 / 7x7 layers bound by the L2 write-REQUEST rate — a store
+// instruction there carries 16 row segments of <= 14 bytes, 4.4 B per request.  With 64 % owq == 0 and RS | OH the 64 lanes
+// of a wave own one CONTIGUOUS output region ((64/owq) strips x RS rows x OW bytes); the results are assembled in LDS
+// and leave as contiguous dwords (256 B per store instruction).
+template <int OUT, int S, int RS, bool TAIL, bool STAGE>
+__device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, uint8_t* wlds) {
+  const bool live = gid_in < a.total_lanes;
+  const long gid = live ? gid_in : a.total_lanes - 1;
   constexpr int NIN = (RS - 1) * S + 3;  // input rows per strip
   constexpr int ND = S == 1 ? 2 : 3;     // dwords per row load
   const int owq = (a.ow + 3) >> 2;
   const int spp = (a.oh + RS - 1) / RS;  // strips per plane
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)a.planes * spp * owq;
-  if (gid >= total) return;
-  const int xq = (int)(gid % owq);
-  const long strip = gid / owq;
-  const int sidx = (int)(strip % spp);
-  const long plane = strip / spp;
-  const int ch = (int)(plane % a.C);
+  // gid -> (plane, strip, quad); shifts when the divisors are powers of two (the common case), wave-uniform choice
+  int xq, sidx, ch;
+  long plane;
+  if (a.fast_div) {
+    xq = (int)(gid & (owq - 1));
+    const long strip = gid >> a.owq_log2;
+    sidx = (int)(strip & (spp - 1));
+    plane = strip >> a.spp_log2;
+    ch = (int)(plane & (a.C - 1));
+  } else {
+    xq = (int)(gid % owq);
+    const long strip = gid / owq;
+    sidx = (int)(strip % spp);
+    plane = strip / spp;
+    ch = (int)(plane % a.C);
+  }
   const int oy0 = sidx * RS;
   const int iy0 = oy0 * S - a.pt;
   const int start = 4 * xq * S - a.pl;       // input column of byte 0 of the row window
   const int sh = start < 0 ? -start : 0;     // bytes of left padding inside the window (only xq == 0)
-  const int lcol = start + sh;               // first column actually loaded
+  int lcol = start + sh;                     // first column actually loaded
+  if (lcol > a.w - 1) lcol = a.w - 1;        // quads entirely right of the image: any legal address, masks are zero
   const long plane_base = plane * (long)a.h * a.w;
-  const long tensor_bytes = (long)a.planes * a.h * a.w;
+  const int8_t* xplane = a.x + plane_base;
+  const long plane_room = (long)a.planes * a.h * a.w - plane_base;
 
   // per-lane validity mask of the ND*4 window bytes (after the left-pad shift): byte i <-> column start + i
   uint32_t cmask[ND];
@@ -309,27 +367,20 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
   // ---- issue every row load of the strip ----
   uint32_t in[NIN][ND];
 #pragma unroll
-  for (int t = 0; t < NIN; ++t) {
-    const int ih = iy0 + t;
-#pragma unroll
-    for (int d = 0; d < ND; ++d) in[t][d] = 0;
-    if (ih >= 0 && ih < a.h && lcol < a.w) {
-      const long gofs = plane_base + (long)ih * a.w + lcol;
-      const int8_t* src = a.x + gofs;
-      if (gofs + 4 * ND <= tensor_bytes) {
-        __builtin_memcpy(&in[t][0], src, 4 * ND);
-      } else {  // the very last bytes of the tensor: never read past the end
-        for (int i = 0; i < 4 * ND; ++i)
-          if (gofs + i < tensor_bytes) in[t][i >> 2] |= (uint32_t)(uint8_t)src[i] << (8 * (i & 3));
-      }
-    }
-  }
-  // filter rows packed (w0, w1, w2, 0), scale, bias
+  for (int t = 0; t < NIN; ++t) dw_load_row<ND, TAIL>(xplane, iy0 + t, a.h, a.w, lcol, sh, plane_room, cmask, in[t]);
+
+  // filter rows packed (w0, w1, w2, 0): three unaligned dword loads; the last one is taken one byte early and shifted so
+  // that it never reads past the end of the filter tensor
   uint32_t wr[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int8_t* wp = a.wt + (size_t)ch * 9 + r * 3;
-    wr[r] = (uint32_t)(uint8_t)wp[0] | ((uint32_t)(uint8_t)wp[1] << 8) | ((uint32_t)(uint8_t)wp[2] << 16);
+  {
+    const int8_t* wp = a.wt + (size_t)ch * 9;
+    uint32_t w0, w1, w2;
+    __builtin_memcpy(&w0, wp, 4);
+    __builtin_memcpy(&w1, wp + 3, 4);
+    __builtin_memcpy(&w2, wp + 5, 4);
+    wr[0] = w0 & 0xffffffu;
+    wr[1] = w1 & 0xffffffu;
+    wr[2] = w2 >> 8;
   }
   const float sc = a.scale ? a.scale[ch] : 1.f;
   const float bi = a.bias ? a.bias[ch] : 0.f;
@@ -342,28 +393,17 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
 
 #pragma unroll
   for (int t = 0; t < NIN; ++t) {
-    uint32_t d[ND];
-#pragma unroll
-    for (int i = 0; i < ND; ++i) d[i] = in[t][i];
-    if (sh) {  // left border lane: make room for the zero padding bytes
-      const int s8 = 8 * sh;
-      if (ND == 3) d[2] = (d[2] << s8) | (d[1] >> (32 - s8));
-      d[1] = (d[1] << s8) | (d[0] >> (32 - s8));
-      d[0] = d[0] << s8;
-    }
-#pragma unroll
-    for (int i = 0; i < ND; ++i) d[i] &= cmask[i];
     uint32_t win[4];
     if (S == 1) {
-      win[0] = d[0];
-      win[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 1);
-      win[2] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
-      win[3] = __builtin_amdgcn_alignbyte(d[1], d[0], 3);
+      win[0] = in[t][0];
+      win[1] = __builtin_amdgcn_alignbyte(in[t][1], in[t][0], 1);
+      win[2] = __builtin_amdgcn_alignbyte(in[t][1], in[t][0], 2);
+      win[3] = __builtin_amdgcn_alignbyte(in[t][1], in[t][0], 3);
     } else {
-      win[0] = d[0];
-      win[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
-      win[2] = d[1];
-      win[3] = __builtin_amdgcn_alignbyte(d[ND - 1], d[1], 2);
+      win[0] = in[t][0];
+      win[1] = __builtin_amdgcn_alignbyte(in[t][1], in[t][0], 2);
+      win[2] = in[t][1];
+      win[3] = __builtin_amdgcn_alignbyte(in[t][ND - 1], in[t][1], 2);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -377,6 +417,52 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
 
   const size_t obase = ((size_t)plane * a.oh + oy0) * a.ow + 4 * xq;
   const int room = a.ow - 4 * xq;
+  if (STAGE && OUT == OUT_I8) {
+    // requantise into registers first (one straight-line body per activation), then LDS, then contiguous stores
+    uint32_t pk[RS];
+    const float hi2r = 254.f, s2 = sc + sc, b2 = bi + bi;
+#define DW_PK(ACTV)                                                                                                  \
+  _Pragma("unroll") for (int o = 0; o < RS; ++o) pk[o] =                                                             \
+      dw_requant4<ACTV>(acc[o], s2, b2, a.alpha, (ACTV == ACT_RELU || ACTV == ACT_RELU6) ? 0.f : -254.f,             \
+                        ACTV == ACT_RELU6 ? fminf(a.alpha + a.alpha, 254.f) : hi2r);
+    switch (a.act) {
+      case ACT_RELU: DW_PK(ACT_RELU) break;
+      case ACT_RELU6: DW_PK(ACT_RELU6) break;
+      case ACT_LEAKY: DW_PK(ACT_LEAKY) break;
+      default: DW_PK(ACT_NONE) break;
+    }
+#undef DW_PK
+    const int lane = threadIdx.x & 63;
+    const int strip_l = lane >> a.owq_log2;              // strip index inside the wave
+    const int lofs = strip_l * (RS * a.ow) + 4 * xq;     // byte offset of (row 0, quad) inside the wave's region
+    if (live) {
+#pragma unroll
+      for (int o = 0; o < RS; ++o) {
+        uint8_t* dst = wlds + lofs + o * a.ow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < room) dst[j] = (uint8_t)(pk[o] >> (8 * j));
+      }
+    }
+    // the wave's region in global memory starts at the output offset of its lane 0
+    const long gid0 = gid_in - lane;
+    const long strip0 = gid0 >> a.owq_log2;
+    const size_t wbase = (size_t)strip0 * (RS * a.ow);
+    const long lanes_left = a.total_lanes - gid0;
+    const int nstrips = (int)((lanes_left < 64 ? lanes_left : 64) >> a.owq_log2);
+    const int region = nstrips * RS * a.ow;  // bytes
+    int8_t* yb = reinterpret_cast<int8_t*>(a.y) + wbase;
+    const int head = (int)((4 - ((uintptr_t)yb & 3)) & 3);  // bytes before the first aligned dword
+    for (int i = lane; i < head && i < region; i += 64) yb[i] = (int8_t)wlds[i];
+    const int ndw = region > head ? (region - head) >> 2 : 0;
+    for (int i = lane; i < ndw; i += 64) {
+      uint32_t v;
+      __builtin_memcpy(&v, wlds + head + 4 * i, 4);
+      *reinterpret_cast<uint32_t*>(yb + head + 4 * i) = v;
+    }
+    for (int i = head + 4 * ndw + lane; i < region; i += 64) yb[i] = (int8_t)wlds[i];
+    return;
+  }
 #define DW_ROWS(ACTV)                                                                              \
   _Pragma("unroll") for (int o = 0; o < RS; ++o) {                                                 \
     if (oy0 + o < a.oh) dw_finish_row<OUT, ACTV>(a, obase + (size_t)o * a.ow, room, acc[o], sc, bi); \
@@ -394,15 +480,50 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
 #undef DW_ROWS
 }
 
+template <int OUT, int S, int RS, bool STAGE>
+__global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dw_stage[];  // STAGE: 4 waves x stage_bytes
+  long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (!STAGE && gid >= a.total_lanes) return;
+  // STAGE: lanes past the end stay (they help with the cooperative copy-out) but are wave-uniformly dropped when the
+  // whole wave is past the end; a dead lane recomputes the last live quad and skips its LDS writes
+  if (STAGE && gid - (threadIdx.x & 63) >= a.total_lanes) return;
+  uint8_t* wlds = STAGE ? dw_stage + (threadIdx.x >> 6) * a.stage_bytes : nullptr;
+  // only the last workgroups can touch the final bytes of the tensor: they alone pay for the guarded loads
+  if (blockIdx.x + 4 >= gridDim.x) dw3x3_direct_body<OUT, S, RS, true, STAGE>(a, gid, wlds);
+  else dw3x3_direct_body<OUT, S, RS, false, STAGE>(a, gid, wlds);
+}
+
 template <int OUT, int S>
-static void launch_dw_direct_s(const DwArgs& a, int rs, hipStream_t s) {
-  const long owq = (a.ow + 3) >> 2;
-  const long spp = (a.oh + rs - 1) / rs;
-  const long total = (long)a.planes * spp * owq;
+static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
+  const long owq = (a_in.ow + 3) >> 2;
+  const long spp = (a_in.oh + rs - 1) / rs;
+  const long total = (long)a_in.planes * spp * owq;
   const unsigned blocks = (unsigned)((total + 255) / 256);
-  if (rs == 8) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 8>), dim3(blocks), dim3(256), 0, s, a);
-  else if (rs == 7) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 7>), dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 4>), dim3(blocks), dim3(256), 0, s, a);
+  DwArgs a = a_in;
+  a.total_lanes = total;
+  auto lg2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return (1L << l) == v ? l : -1; };
+  a.owq_log2 = lg2(owq);
+  a.spp_log2 = lg2(spp);
+  a.fast_div = a.owq_log2 >= 0 && a.spp_log2 >= 0 && lg2(a.C) >= 0;
+  // output staging through LDS: int8 output, narrow planes, a wave = whole strips, strips = whole rows of the plane
+  static int stage_env = -1;
+  if (stage_env < 0) {
+    const char* e = getenv("PLHIP_DW_STAGE");
+    stage_env = e ? atoi(e) : 1;
+  }
+  const bool stage = stage_env && OUT == OUT_I8 && a.ow <= 64 && a.owq_log2 >= 0 && owq <= 64 && a.oh % rs == 0;
+  a.stage_bytes = stage ? (int)(((64 / owq) * rs * a.ow + 15) & ~15) : 0;
+  const size_t lds = stage ? (size_t)4 * a.stage_bytes : 0;
+  if (stage) {
+    if (rs == 8) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 8, true>), dim3(blocks), dim3(256), lds, s, a);
+    else if (rs == 7) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 7, true>), dim3(blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 4, true>), dim3(blocks), dim3(256), lds, s, a);
+    return;
+  }
+  if (rs == 8) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 8, false>), dim3(blocks), dim3(256), 0, s, a);
+  else if (rs == 7) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 7, false>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 4, false>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 static bool launch_dw_direct(const DwArgs& a, int out, hipStream_t s) {

@@ -44,6 +44,9 @@ struct DwArgs {
   int bands;    // bands per plane
   int in_rows;  // staged input rows per band
   int pitch;    // LDS row pitch in bytes (multiple of 4)
+  long total_lanes;               // direct kernel: planes * strips * quads
+  int owq_log2, spp_log2, fast_div;  // direct kernel: power-of-two index split
+  int stage_bytes;                // direct kernel: LDS bytes per wave for output staging (0 = off)
   int act;
   float alpha;
 };
