@@ -9,8 +9,11 @@
 //     masks); the 4 three-byte windows are cut with v_alignbyte_b32;
 //   * the packed filter rows (w0,w1,w2,0) of the whole layer sit in LDS ([ci*3+r][cout] dwords, broadcast reads);
 //     MACs are v_dot4_i32_i8; outputs leave as one dword per (lane, channel, row): 32 lanes x 4 B coalesced.
+#include <stdlib.h>
+
 #include "plhip_device.h"
 #include "plhip_kernels.h"
+#include "gemm_epilogue.h"
 
 namespace plhip {
 
@@ -22,7 +25,10 @@ bool conv3x3s2_direct_supported(int cin, int cout, int kh, int kw, int sh, int s
          pl <= 3;
 }
 
-size_t conv3x3s2_direct_packed_bytes(int cin, int cout) { return (size_t)cin * 3 * ((cout + 3) / 4 * 4) * 4; }
+// packed block = [dot4 layout: cin*3 x coutp dwords][MFMA A fragments: ceil(cout/32) x 1 KiB] — both are always written,
+// the kernel is picked per launch (the MFMA form needs Cin*9 <= 32 and OW % 4 == 0)
+static size_t ds2_dot4_bytes(int cin, int cout) { return (size_t)cin * 3 * ((cout + 3) / 4 * 4) * 4; }
+size_t conv3x3s2_direct_packed_bytes(int cin, int cout) { return ds2_dot4_bytes(cin, cout) + (size_t)((cout + 31) / 32) * 1024; }
 
 __global__ void pack_conv3x3s2_direct_kernel(const int8_t* __restrict__ w, uint32_t* __restrict__ wp, int cin, int cout, int coutp) {
   const int total = cin * 3 * coutp;
@@ -89,8 +95,8 @@ __device__ __forceinline__ void ds2_store(const DirectS2Args& a, size_t off, int
 }
 
 template <int OUT, int ACT>
-__device__ __forceinline__ void ds2_body(const DirectS2Args& a, const uint32_t* lw, const uint32_t (&win)[DS2_MAXCIN * 3][4],
-                                         int b, int oy, int xq) {
+__device__ __forceinline__ void ds2_body(const DirectS2Args& a, const uint32_t* lw, const float* lsb,
+                                         const uint32_t (&win)[DS2_MAXCIN * 3][4], int b, int oy, int xq) {
   const int room = a.ow - 4 * xq;
   const size_t plane = (size_t)a.oh * a.ow;
   for (int cb = 0; cb < a.cout; cb += DS2_COB) {  // uniform loop
@@ -116,8 +122,9 @@ __device__ __forceinline__ void ds2_body(const DirectS2Args& a, const uint32_t* 
     for (int c = 0; c < DS2_COB; ++c) {
       const int co = cb + c;
       if (co >= a.cout) break;  // uniform
-      const float s = (OUT == OUT_I32) ? 1.f : a.scale[co];
-      const float bi = (OUT != OUT_I32 && a.bias) ? a.bias[co] : 0.f;
+      // scale / bias from LDS: a global load here would queue behind the previous channels' stores (in-order vmcnt)
+      const float s = lsb[co];
+      const float bi = lsb[a.coutp + co];
       const size_t off = ((size_t)b * a.cout + co) * plane + (size_t)oy * a.ow + 4 * xq;
       ds2_store<OUT, ACT>(a, off, room, acc[c], s, bi);
     }
@@ -129,6 +136,11 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(DirectS2Args a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lw[];  // [cin*3][coutp (+ room so that a COB block never runs off)]
   const int wtotal = a.cin * 3 * a.coutp;
   for (int i = threadIdx.x; i < wtotal + DS2_COB; i += 256) lw[i] = i < wtotal ? a.wp[i] : 0u;
+  float* lsb = reinterpret_cast<float*>(lw + wtotal + DS2_COB);  // [coutp] scales, [coutp] biases
+  for (int i = threadIdx.x; i < a.coutp; i += 256) {
+    lsb[i] = (OUT != OUT_I32 && a.scale && i < a.cout) ? a.scale[i] : 1.f;
+    lsb[a.coutp + i] = (OUT != OUT_I32 && a.bias && i < a.cout) ? a.bias[i] : 0.f;
+  }
   __syncthreads();
 
   const int owq = (a.ow + 3) >> 2;
@@ -191,14 +203,173 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(DirectS2Args a) {
   }
 
   if (OUT == OUT_I32) {
-    ds2_body<OUT, ACT_NONE>(a, lw, win, b, oy, xq);
+    ds2_body<OUT, ACT_NONE>(a, lw, lsb, win, b, oy, xq);
     return;
   }
   switch (a.act) {
-    case ACT_RELU: ds2_body<OUT, ACT_RELU>(a, lw, win, b, oy, xq); break;
-    case ACT_RELU6: ds2_body<OUT, ACT_RELU6>(a, lw, win, b, oy, xq); break;
-    case ACT_LEAKY: ds2_body<OUT, ACT_LEAKY>(a, lw, win, b, oy, xq); break;
-    default: ds2_body<OUT, ACT_NONE>(a, lw, win, b, oy, xq); break;
+    case ACT_RELU: ds2_body<OUT, ACT_RELU>(a, lw, lsb, win, b, oy, xq); break;
+    case ACT_RELU6: ds2_body<OUT, ACT_RELU6>(a, lw, lsb, win, b, oy, xq); break;
+    case ACT_LEAKY: ds2_body<OUT, ACT_LEAKY>(a, lw, lsb, win, b, oy, xq); break;
+    default: ds2_body<OUT, ACT_NONE>(a, lw, lsb, win, b, oy, xq); break;
+  }
+}
+
+// =====================================================================================================================
+// MFMA form of the stem (Cin*9 <= 32, OW % 4 == 0): PMC on the dot4 kernel showed ~2900 VALU per wave, 22 per output,
+// most of them the 9 v_dot4 per output.  Here the 27 taps become ONE K-step of v_mfma_i32_32x32x32_i8: the row windows
+// are gathered exactly as above, but instead of multiplying them they are re-packed (one v_perm per operand dword) into
+// the MFMA B fragment, k = ci*9 + r*3 + q.  Lane (c, h): c = quad (4 consecutive ox, one per MFMA i), h = k half.  The
+// 32 couts of a tile are the MFMA rows; the epilogue is the GEMM one (4 consecutive ox per lane -> one dword store).
+template <int BASE>
+__device__ __forceinline__ uint32_t ds2_kdword(const uint32_t (&w)[DS2_MAXCIN * 3], int K) {
+  // operand bytes k = BASE .. BASE+3 ; byte k lives in window k/3, position k%3
+  constexpr int cr0 = BASE / 3;
+  uint32_t sel = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = BASE + t;
+    const int cr = k / 3, q = k - 3 * cr;
+    const uint32_t sb = (k < K && cr < DS2_MAXCIN * 3) ? (uint32_t)(q + (cr == cr0 ? 0 : 4)) : 0x0cu;  // 0x0c -> constant 0
+    sel |= sb << (8 * t);
+  }
+  const uint32_t lo = w[cr0 < DS2_MAXCIN * 3 ? cr0 : 0];
+  const uint32_t hi = w[cr0 + 1 < DS2_MAXCIN * 3 ? cr0 + 1 : 0];
+  return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+template <int OUT, bool VEC_STORE>
+__global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, const int8_t* __restrict__ afrag) {
+  __shared__ __attribute__((aligned(16))) float lsb_all[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int owq = a.ow >> 2;  // OW % 4 == 0 here
+  const long total = (long)a.n * a.oh * owq;
+  const long wtile = (long)blockIdx.x * 4 + wave;
+  if (wtile * 32 >= total) return;
+  long quad = wtile * 32 + c;
+  const bool qvalid = quad < total;
+  if (!qvalid) quad = total - 1;
+  const int xq = (int)(quad % owq);
+  const long t = quad / owq;
+  const int oy = (int)(t % a.oh);
+  const int b = (int)(t / a.oh);
+  const int start = 8 * xq - a.pl;
+  const int sh = start < 0 ? -start : 0;
+  int lcol = start + sh;
+  if (lcol > a.w - 1) lcol = a.w - 1;
+  const long tensor_bytes = (long)a.n * a.cin * a.h * a.w;
+  const int K = a.cin * 9;
+
+  // everything that does not depend on the image goes first, so that its latency overlaps the input loads
+  GemmArgs g;
+  g.y = a.y;
+  g.scale = a.scale;
+  g.bias = a.bias;
+  g.M = a.cout;
+  g.HWY = a.oh * a.ow;
+  g.y_bstride = (size_t)a.cout * a.oh * a.ow;
+  g.act = a.act;
+  g.alpha = a.alpha;
+  float* lsb = lsb_all[wave];
+  const v4i af0 = *reinterpret_cast<const v4i*>(afrag + (size_t)lane * 16);
+  if (OUT != OUT_I32) stage_scale_bias<1>(g, 0, lane, lsb);
+
+  uint32_t cmask[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = start + 4 * d + i;
+      if (col >= 0 && col < a.w) m |= 0xffu << (8 * i);
+    }
+    cmask[d] = m;
+  }
+  // row windows, as in the dot4 kernel (both k-halves of a column need all of them for the re-pack)
+  uint32_t win[4][DS2_MAXCIN * 3];  // [j][cr]
+#pragma unroll
+  for (int cr = 0; cr < DS2_MAXCIN * 3; ++cr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) win[j][cr] = 0;
+    if (cr >= a.cin * 3) continue;  // uniform
+    const int ci = cr / 3, r = cr - 3 * (cr / 3);
+    const int ih = 2 * oy - a.pt + r;
+    const bool rv = ih >= 0 && ih < a.h;
+    const int ihc = ih < 0 ? 0 : (ih >= a.h ? a.h - 1 : ih);
+    uint32_t d[3] = {0, 0, 0};
+    const long gofs = (((long)b * a.cin + ci) * a.h + ihc) * a.w + lcol;
+    const int8_t* src = a.x + gofs;
+    if (gofs + 12 <= tensor_bytes) {
+      __builtin_memcpy(d, src, 12);
+    } else {
+      for (int i = 0; i < 12; ++i)
+        if (gofs + i < tensor_bytes) d[i >> 2] |= (uint32_t)(uint8_t)src[i] << (8 * (i & 3));
+    }
+    if (sh) {
+      const int s8 = 8 * sh;
+      d[2] = (d[2] << s8) | (d[1] >> (32 - s8));
+      d[1] = (d[1] << s8) | (d[0] >> (32 - s8));
+      d[0] = d[0] << s8;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = rv ? (d[i] & cmask[i]) : 0u;
+    win[0][cr] = d[0];
+    win[1][cr] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
+    win[2][cr] = d[1];
+    win[3][cr] = __builtin_amdgcn_alignbyte(d[2], d[1], 2);
+  }
+  // B fragments: lane half h holds k = 16h .. 16h+15
+  v4i bf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t l0 = ds2_kdword<0>(win[j], K), l1 = ds2_kdword<4>(win[j], K), l2 = ds2_kdword<8>(win[j], K),
+                   l3 = ds2_kdword<12>(win[j], K);
+    const uint32_t u0 = ds2_kdword<16>(win[j], K), u1 = ds2_kdword<20>(win[j], K), u2 = ds2_kdword<24>(win[j], K),
+                   u3 = ds2_kdword<28>(win[j], K);
+    bf[j][0] = (int)(h ? u0 : l0);
+    bf[j][1] = (int)(h ? u1 : l1);
+    bf[j][2] = (int)(h ? u2 : l2);
+    bf[j][3] = (int)(h ? u3 : l3);
+  }
+
+  const int hw = oy * a.ow + 4 * xq;
+  const int MT = (a.cout + 31) >> 5;
+  for (int mt = 0; mt < MT; ++mt) {  // uniform
+    v4i af = af0;
+    if (mt > 0) {
+      af = *reinterpret_cast<const v4i*>(afrag + ((size_t)mt * 64 + lane) * 16);
+      if (OUT != OUT_I32) stage_scale_bias<1>(g, mt, lane, lsb);
+    }
+    v16i acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0;
+      acc[0][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[0][j], 0, 0, 0);
+    }
+    if (qvalid) {
+      if (OUT == OUT_I32) {
+        gemm_epilogue<1, OUT, VEC_STORE, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
+      } else {
+        switch (a.act) {
+          case ACT_RELU: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_RELU>(g, acc, mt, h, b, hw, lsb); break;
+          case ACT_RELU6: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_RELU6>(g, acc, mt, h, b, hw, lsb); break;
+          case ACT_LEAKY: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb); break;
+          default: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb); break;
+        }
+      }
+    }
+  }
+}
+
+// A fragments: tile mt, lane (r = lane&31, h = lane>>5), byte j  <-  W[mt*32 + r][k = 16h + j], k = ci*9 + r3*3 + q
+__global__ void pack_conv3x3s2_mfma_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ afrag, int cin, int cout) {
+  const int total = ((cout + 31) / 32) * 1024;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx & 15, lane = (idx >> 4) & 63, mt = idx >> 10;
+    const int co = mt * 32 + (lane & 31), k = 16 * (lane >> 5) + j;
+    afrag[idx] = (co < cout && k < cin * 9) ? w[(size_t)co * cin * 9 + k] : (int8_t)0;
   }
 }
 
@@ -206,13 +377,31 @@ void launch_pack_conv3x3s2_direct(const int8_t* w_oihw, uint32_t* wp, int cin, i
   const int coutp = (cout + 3) / 4 * 4;
   const int total = cin * 3 * coutp;
   hipLaunchKernelGGL(pack_conv3x3s2_direct_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w_oihw, wp, cin, cout, coutp);
+  int8_t* afrag = reinterpret_cast<int8_t*>(wp) + ds2_dot4_bytes(cin, cout);
+  const int ftotal = ((cout + 31) / 32) * 1024;
+  hipLaunchKernelGGL(pack_conv3x3s2_mfma_kernel, dim3((ftotal + 255) / 256), dim3(256), 0, s, w_oihw, afrag, cin, cout);
 }
 
 void launch_conv3x3s2_direct(const DirectS2Args& a, int out, hipStream_t s) {
+  static int mfma_env = -1;
+  if (mfma_env < 0) {
+    const char* e = getenv("PLHIP_STEM_MFMA");
+    mfma_env = e ? atoi(e) : 1;
+  }
+  const size_t esz = out == OUT_I8 ? 1 : 4;
+  if (mfma_env && a.cin * 9 <= 32 && (a.ow & 3) == 0 && ((uintptr_t)a.y & (4 * esz - 1)) == 0) {
+    const long quads = (long)a.n * a.oh * (a.ow >> 2);
+    const unsigned blocks = (unsigned)((quads + 127) / 128);
+    const int8_t* afrag = reinterpret_cast<const int8_t*>(a.wp) + ds2_dot4_bytes(a.cin, a.cout);
+    if (out == OUT_I32) hipLaunchKernelGGL((conv3x3s2_mfma_kernel<OUT_I32, true>), dim3(blocks), dim3(256), 0, s, a, afrag);
+    else if (out == OUT_F32) hipLaunchKernelGGL((conv3x3s2_mfma_kernel<OUT_F32, true>), dim3(blocks), dim3(256), 0, s, a, afrag);
+    else hipLaunchKernelGGL((conv3x3s2_mfma_kernel<OUT_I8, true>), dim3(blocks), dim3(256), 0, s, a, afrag);
+    return;
+  }
   const long owq = (a.ow + 3) >> 2;
   const long total = (long)a.n * a.oh * owq;
   const unsigned blocks = (unsigned)((total + 255) / 256);
-  const size_t lds = ((size_t)a.cin * 3 * a.coutp + DS2_COB) * 4;
+  const size_t lds = ((size_t)a.cin * 3 * a.coutp + DS2_COB + 2 * a.coutp) * 4;
   if (out == OUT_I32) hipLaunchKernelGGL((conv3x3s2_direct_kernel<OUT_I32>), dim3(blocks), dim3(256), lds, s, a);
   else if (out == OUT_F32) hipLaunchKernelGGL((conv3x3s2_direct_kernel<OUT_F32>), dim3(blocks), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv3x3s2_direct_kernel<OUT_I8>), dim3(blocks), dim3(256), lds, s, a);

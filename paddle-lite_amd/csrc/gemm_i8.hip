@@ -27,6 +27,7 @@
 
 #include "plhip_device.h"
 #include "plhip_kernels.h"
+#include "gemm_epilogue.h"
 
 namespace plhip {
 
@@ -65,130 +66,6 @@ __device__ __forceinline__ void load_b(const int8_t* __restrict__ xb, int ks, in
   }
 }
 
-// ---- epilogue ----------------------------------------------------------------------------------------------
-// C/D layout of the 32x32 MFMA: col = lane&31 (-> n = 4c+i), row = (r&3) + 8*(r>>2) + 4*(lane>>5).  For register
-// group gq = r>>2 a lane therefore owns 4 CONSECUTIVE rows 8gq + 4h + (0..3): their scales / biases are one 16-byte
-// load each (same address for the 32 lanes of a half-wave).  The activation is a template parameter so that the
-// 128 outputs of a lane are processed by straight-line code (no per-element branches).
-//
-// int8 requantisation works on DOUBLED values: y2 = fma(acc, 2s, 2b) = 2y exactly (power-of-two scaling commutes
-// with rounding), t = trunc(clamp(y2)), q = round_half_away(y) = (t + 1 + (t>>31)) >> 1.  For relu / relu6 the values
-// are non-negative, so the four results are packed first and (+1, >>1) is applied to the 4 bytes at once.
-template <int ACT>
-__device__ __forceinline__ float act2(float y2, float alpha) {  // activation on the doubled value
-  if (ACT == ACT_LEAKY) return y2 > 0.f ? y2 : alpha * y2;      // alpha*(2y) == 2*(alpha*y)
-  return y2;                                                    // relu / relu6 are folded into the clamp
-}
-
-template <int MA, int OUT, bool VEC_STORE, bool MFULL, int ACT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&acc)[MA][4], int mt, int h, int b, int hw,
-                                              const float* lsb) {
-  const int hwy_room = g.HWY - hw;  // columns hw+i with i < hwy_room are real outputs (im2col pitch pad)
-  const size_t ybase = (size_t)b * g.y_bstride + hw;
-  const float hi2 = ACT == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
-  const float lo2 = (ACT == ACT_RELU || ACT == ACT_RELU6) ? 0.f : -254.f;
-#pragma unroll
-  for (int a = 0; a < MA; ++a) {
-    const int mbase = (mt * MA + a) * 32;
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int m0 = mbase + 8 * gq + 4 * h;
-      if (!MFULL && m0 >= g.M) continue;
-      // scale / bias come from LDS (staged at kernel start): a global load here would sit behind the previous rows'
-      // stores in the in-order vmcnt queue and serialise the epilogue into one memory round trip per row group
-      v4f sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-      if (OUT != OUT_I32) {
-        sc = *reinterpret_cast<const v4f*>(lsb + a * 32 + 8 * gq + 4 * h);
-        bi = *reinterpret_cast<const v4f*>(lsb + MA * 32 + a * 32 + 8 * gq + 4 * h);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * gq + e;
-        const int m = m0 + e;
-        if (!MFULL && m >= g.M) continue;
-        const int v0 = acc[a][0][r], v1 = acc[a][1][r], v2 = acc[a][2][r], v3 = acc[a][3][r];
-        const size_t yoff = ybase + (uint32_t)(m * g.HWY);  // one image's output is < 2^31 elements (checked on the host)
-        if (OUT == OUT_I32) {
-          int* yp = reinterpret_cast<int*>(g.y) + yoff;
-          if (VEC_STORE) {
-            v4i v = {v0, v1, v2, v3};
-            *reinterpret_cast<v4i*>(yp) = v;
-          } else {
-            if (0 < hwy_room) yp[0] = v0;
-            if (1 < hwy_room) yp[1] = v1;
-            if (2 < hwy_room) yp[2] = v2;
-            if (3 < hwy_room) yp[3] = v3;
-          }
-        } else if (OUT == OUT_F32) {
-          const float s = sc[e], bb = bi[e];
-          float f[4] = {__fmaf_rn((float)v0, s, bb), __fmaf_rn((float)v1, s, bb), __fmaf_rn((float)v2, s, bb),
-                        __fmaf_rn((float)v3, s, bb)};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (ACT == ACT_RELU) f[i] = fmaxf(f[i], 0.f);
-            if (ACT == ACT_RELU6) f[i] = fminf(fmaxf(f[i], 0.f), g.alpha);
-            if (ACT == ACT_LEAKY) f[i] = f[i] > 0.f ? f[i] : g.alpha * f[i];
-          }
-          float* yp = reinterpret_cast<float*>(g.y) + yoff;
-          if (VEC_STORE) {
-            v4f v = {f[0], f[1], f[2], f[3]};
-            *reinterpret_cast<v4f*>(yp) = v;
-          } else {
-            if (0 < hwy_room) yp[0] = f[0];
-            if (1 < hwy_room) yp[1] = f[1];
-            if (2 < hwy_room) yp[2] = f[2];
-            if (3 < hwy_room) yp[3] = f[3];
-          }
-        } else {
-          const float s2 = sc[e] + sc[e], b2 = bi[e] + bi[e];
-          const int vv[4] = {v0, v1, v2, v3};
-          uint32_t packed;
-          if (ACT == ACT_RELU || ACT == ACT_RELU6) {
-            uint32_t t[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              t[i] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)vv[i], s2, b2), lo2, hi2);  // trunc, 0..254
-            const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-            packed = ((p + 0x01010101u) >> 1) & 0x7f7f7f7fu;
-          } else {
-            int q[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float y2 = __builtin_amdgcn_fmed3f(act2<ACT>(__fmaf_rn((float)vv[i], s2, b2), g.alpha), lo2, hi2);
-              const int t = (int)y2;
-              q[i] = (t + 1 + (t >> 31)) >> 1;
-            }
-            packed = pack4_i8(q[0], q[1], q[2], q[3]);
-          }
-          int8_t* yp = reinterpret_cast<int8_t*>(g.y) + yoff;
-          if (VEC_STORE) {
-            *reinterpret_cast<uint32_t*>(yp) = packed;
-          } else {
-            if (0 < hwy_room) yp[0] = (int8_t)(packed & 0xff);
-            if (1 < hwy_room) yp[1] = (int8_t)((packed >> 8) & 0xff);
-            if (2 < hwy_room) yp[2] = (int8_t)((packed >> 16) & 0xff);
-            if (3 < hwy_room) yp[3] = (int8_t)(packed >> 24);
-          }
-        }
-      }
-    }
-  }
-}
-
-// Stage this wave's MA*32 folded scales and biases into LDS: lsb[0 .. MA*32) scales, lsb[MA*32 .. 2*MA*32) biases.
-template <int MA>
-__device__ __forceinline__ void stage_scale_bias(const GemmArgs& g, int mt, int lane, float* lsb) {
-#pragma unroll
-  for (int t = 0; t < (MA * 32 + 63) / 64; ++t) {
-    const int j = t * 64 + lane;
-    if (j < MA * 32) {
-      const int m = mt * MA * 32 + j;
-      lsb[j] = (g.scale && m < g.M) ? g.scale[m] : 1.f;
-      lsb[MA * 32 + j] = (g.bias && m < g.M) ? g.bias[m] : 0.f;
-    }
-  }
-}
-
 template <int MA, int OUT, bool VEC_STORE, bool MFULL, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
@@ -199,7 +76,6 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   const int nt = (int)(wid / g.MT);
   __shared__ __attribute__((aligned(16))) float lsb_all[4][2 * MA * 32];
   float* lsb = lsb_all[wave];
-  if (OUT != OUT_I32) stage_scale_bias<MA>(g, mt, lane, lsb);
   const int c = lane & 31, h = lane >> 5;
   const int ntot = g.NB * g.HWX;  // multiple of 4 by construction
 
@@ -223,6 +99,8 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   v4i af[MA];
   load_b<ALIGNED>(xb, 0, h, g.K, g.XP, room, raw);
   load_a<MA>(g.wp, mt, g.KS, 0, lane, af);
+  float my_s = 1.f, my_b = 0.f;  // this lane's share of the tile's scale / bias, issued behind the first operand loads
+  if (OUT != OUT_I32) load_scale_bias<MA>(g, mt, lane, my_s, my_b);
 
   for (int ks = 0; ks < ((g.dbg & 2) ? 0 : g.KS); ++ks) {
     v4i bf[4];
@@ -249,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
         acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[a], bf[i], acc[a][i], 0, 0, 0);
   }
 
+  if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
   if (!nvalid || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
     gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
@@ -284,7 +163,6 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
   const bool mactive = mt < g.MT;  // wave-uniform; inactive waves still load their share of B and hit the barriers
   const int mtc = mactive ? mt : g.MT - 1;
   float* lsb = lsb_all[wave];
-  if (OUT != OUT_I32) stage_scale_bias<MA>(g, mtc, lane, lsb);
   const int c = lane & 31, h = lane >> 5;
   const int ntot = g.NB * g.HWX;
 
@@ -340,6 +218,8 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
   if (wave < KS) load_b<ALIGNED>(xb, wave, h, g.K, g.XP, room, raw);
   load_a_c(0, a0);
   load_a_c(1, a1);
+  float my_s = 1.f, my_b = 0.f;
+  if (OUT != OUT_I32) load_scale_bias<MA>(g, mtc, lane, my_s, my_b);
   if (wave < KS) stage_write(0);
   __syncthreads();
 
@@ -362,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
     __syncthreads();
   }
 
+  if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
   if (!nvalid || !mactive || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
     gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
@@ -451,8 +332,9 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
 #pragma unroll
   for (int p = 0; p < GD_D - 1; ++p)
     if (p < KS) issue(p, p);
-  // scale / bias -> LDS behind the prologue DMA (their wait then coincides with the first K-step's)
-  if (OUT != OUT_I32) stage_scale_bias<MA>(g, mtc, lane, lsb);
+  // scale / bias: plain loads behind the prologue DMA; they reach LDS after the K loop
+  float my_s = 1.f, my_b = 0.f;
+  if (OUT != OUT_I32) load_scale_bias<MA>(g, mtc, lane, my_s, my_b);
 
   // Software pipeline inside the wave: while the MFMAs of K-step ks run on the matrix pipe, the raw rows of K-step
   // ks+1 are read from LDS and transposed on the VALU (independent instruction streams the scheduler interleaves).
@@ -528,6 +410,7 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
     for (int a = 0; a < MA; ++a) af_cur[a] = af_nxt[a];
   }
 
+  if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
   if (!nvalid || !mactive || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
     gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);

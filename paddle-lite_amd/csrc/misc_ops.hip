@@ -76,50 +76,55 @@ __global__ __launch_bounds__(256) void fc_i8_kernel(const int8_t* __restrict__ x
   }
 }
 
-// Fast path (k % 4 == 0, x 4-byte aligned): a 256-thread block owns 64 output columns x FCF_MB rows; its 4 waves split
-// the k-quads, x dwords are wave-uniform (scalar loads feeding v_dot4_i32_i8), partial sums meet in LDS.
+// Fast path (k % 16 == 0, x 16-byte aligned): a 256-thread block owns 64 output columns x FCF_MB rows.  The block
+// first stages its FCF_MB x-rows into LDS with coalesced 16-byte loads (scalar loads of x were latency bound: 16
+// dependent s_load per round).  Its 4 waves then split the k range; per round a lane reads 4 packed weight dwords
+// (coalesced: lanes walk n) and each x quad-quad comes from LDS as one broadcast ds_read_b128.  Partial sums of the 4
+// waves meet in LDS (the x tile's space is reused after a barrier).
 #define FCF_MB 16
 template <int OUT>
 __global__ __launch_bounds__(256) void fc_i8_fast_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ wp,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
                                                          void* __restrict__ y, int m, int k, int n, int relu) {
-  __shared__ int red[4][FCF_MB][64];
+  extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];  // max(FCF_MB * k, 4 * FCF_MB * 64 * 4) bytes
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = blockIdx.x * 64 + lane;
   const int m0 = blockIdx.y * FCF_MB;
   const int k4n = k >> 2;
-  const int q0 = (k4n * wave) / 4, q1 = (k4n * (wave + 1)) / 4;
+  const int k16n = k >> 4;
+  // ---- stage x rows m0 .. m0+FCF_MB-1 ----
+  {
+    const v4i* src = reinterpret_cast<const v4i*>(x);
+    v4i* dst = reinterpret_cast<v4i*>(fsm);
+    for (int i = threadIdx.x; i < FCF_MB * k16n; i += 256) {
+      const int r = i / k16n, c16 = i - r * k16n;
+      const int mi = m0 + r < m ? m0 + r : m - 1;
+      dst[i] = src[(size_t)mi * k16n + c16];
+    }
+  }
+  __syncthreads();
+  const int g0 = (k16n * wave) / 4, g1 = (k16n * (wave + 1)) / 4;  // this wave's 16-byte k groups
   const int colc = col < n ? col : n - 1;
   const uint32_t* wq = reinterpret_cast<const uint32_t*>(wp) + colc;
-  const uint32_t* xq = reinterpret_cast<const uint32_t*>(x);
   int acc[FCF_MB];
 #pragma unroll
   for (int i = 0; i < FCF_MB; ++i) acc[i] = 0;
-  int kq = q0;
-  for (; kq + 4 <= q1; kq += 4) {  // 4 k-quads per round: 4 vector loads of w, one 16-byte scalar load of x per row
+  for (int gq = g0; gq < g1; ++gq) {
     int wv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) wv[u] = (int)wq[(size_t)(kq + u) * n];
+    for (int u = 0; u < 4; ++u) wv[u] = (int)wq[(size_t)(gq * 4 + u) * n];
 #pragma unroll
     for (int i = 0; i < FCF_MB; ++i) {
-      const int mi = m0 + i < m ? m0 + i : m - 1;  // wave-uniform
-      const uint32_t* xr = xq + (size_t)mi * k4n + kq;
+      const v4i xv = *reinterpret_cast<const v4i*>(fsm + ((size_t)i * k16n + gq) * 16);  // same address in every lane
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[i] = __builtin_amdgcn_sdot4((int)xr[u], wv[u], acc[i], false);
+      for (int u = 0; u < 4; ++u) acc[i] = __builtin_amdgcn_sdot4(xv[u], wv[u], acc[i], false);
     }
   }
-  for (; kq < q1; ++kq) {
-    const int wv = (int)wq[(size_t)kq * n];
+  __syncthreads();  // everyone is done with the x tile: reuse the space for the cross-wave reduction
+  int* red = reinterpret_cast<int*>(fsm);
 #pragma unroll
-    for (int i = 0; i < FCF_MB; ++i) {
-      const int mi = m0 + i < m ? m0 + i : m - 1;  // wave-uniform
-      const int xv = (int)xq[(size_t)mi * k4n + kq];
-      acc[i] = __builtin_amdgcn_sdot4(xv, wv, acc[i], false);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < FCF_MB; ++i) red[wave][i][lane] = acc[i];
+  for (int i = 0; i < FCF_MB; ++i) red[(wave * FCF_MB + i) * 64 + lane] = acc[i];
   __syncthreads();
   if (col >= n) return;
   const float s = (OUT == OUT_I32) ? 1.f : scale[col];
@@ -128,7 +133,8 @@ __global__ __launch_bounds__(256) void fc_i8_fast_kernel(const int8_t* __restric
   for (int j = 0; j < FCF_MB / 4; ++j) {
     const int i = wave * (FCF_MB / 4) + j;
     if (m0 + i >= m) break;
-    const int a = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
+    const int a = red[(0 * FCF_MB + i) * 64 + lane] + red[(1 * FCF_MB + i) * 64 + lane] + red[(2 * FCF_MB + i) * 64 + lane] +
+                  red[(3 * FCF_MB + i) * 64 + lane];
     const size_t off = (size_t)(m0 + i) * n + col;
     if (OUT == OUT_I32) {
       reinterpret_cast<int*>(y)[off] = a;
@@ -217,11 +223,12 @@ void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s)
 
 void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const float* bias, void* y, int m, int k, int n,
                int relu, int out, hipStream_t s) {
-  if ((k & 3) == 0 && ((uintptr_t)x & 3) == 0) {
+  const size_t lds = (size_t)FCF_MB * k > (size_t)4 * FCF_MB * 64 * 4 ? (size_t)FCF_MB * k : (size_t)4 * FCF_MB * 64 * 4;
+  if ((k & 15) == 0 && ((uintptr_t)x & 15) == 0 && lds <= 64 * 1024) {
     dim3 grid((n + 63) / 64, (m + FCF_MB - 1) / FCF_MB);
-    if (out == OUT_I32) hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_I32>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
-    else if (out == OUT_F32) hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_F32>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
-    else hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_I8>), grid, dim3(256), 0, s, x, wp, scale, bias, y, m, k, n, relu);
+    if (out == OUT_I32) hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_I32>), grid, dim3(256), lds, s, x, wp, scale, bias, y, m, k, n, relu);
+    else if (out == OUT_F32) hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_F32>), grid, dim3(256), lds, s, x, wp, scale, bias, y, m, k, n, relu);
+    else hipLaunchKernelGGL((fc_i8_fast_kernel<OUT_I8>), grid, dim3(256), lds, s, x, wp, scale, bias, y, m, k, n, relu);
     return;
   }
   dim3 grid((n + 255) / 256, (m + FC_MB - 1) / FC_MB);
