@@ -260,16 +260,21 @@ def main():
         dom = max(fam_out, key=lambda k: fam_out[k]["ms"])
         d = fam_out[dom]
         hbm_frac = d["GB/s"] / HBM_PEAK_GBS
+        # HBM-side traffic per launch from the committed PMC passes (tools/pmc_traffic.py over `rocprofv3 --pmc FETCH_SIZE`
+        # and `--pmc WRITE_SIZE` runs of this script, batch 128): FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B;
+        # verified here on calib_f32_to_i8 and on the 32->64 pointwise layer, both = 0.50 of the known bytes) + WRITE_SIZE
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.batch == 128:
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                t_ = json.load(open(tpath)).get(dom)
+                traffic = round(t_["fetch_bytes_per_launch_x2"] + t_["write_bytes_per_launch"]) if t_ else None
             except Exception:
                 traffic = None
         roof = {"kernel": dom, "bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(hbm_frac, 4), "traffic": traffic,
                 "avg_launch_ms": round(d["ms"] / d["launches"], 5), "launches_per_step": d["launches"],
+                "alg_bytes_per_launch": round(d["alg_bytes"] / d["launches"]),
                 "mfma_TOP/s": d["TOP/s"], "mfma_frac_of_dense_i8_peak": round(d["TOP/s"] / MFMA_I8_PEAK_TOPS, 4),
                 "note": "algorithmic bytes = int8 in + out + weights once per layer (SURVEY.md 8d), summed over the "
                         "family's launches of one step, / summed launch time (HIP events on the launch stream)"}

@@ -157,8 +157,13 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mtb_n = (g.MT + 3) >> 2;  // blocks along M
-  const int mtb = blockIdx.x % mtb_n;
-  const int nt = blockIdx.x / mtb_n;
+  // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the mtb_n blocks that
+  // share one B tile get ids that are equal mod 8 (same XCD, adjacent in dispatch order): the tile crosses the fabric
+  // once instead of mtb_n times (PMC: FETCH_SIZE was 3.4x the algorithmic bytes on the M = 512 layers).
+  const int grp = blockIdx.x / (8 * mtb_n), rem = blockIdx.x - grp * (8 * mtb_n);
+  const int mtb = rem >> 3;
+  const int nt = grp * 8 + (rem & 7);
+  if (nt >= g.NT) return;  // block-uniform (grid is padded to 8 N-tiles)
   const int mt = mtb * 4 + wave;
   const bool mactive = mt < g.MT;  // wave-uniform; inactive waves still load their share of B and hit the barriers
   const int mtc = mactive ? mt : g.MT - 1;
@@ -288,8 +293,13 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mtb_n = (g.MT + 3) >> 2;
-  const int mtb = blockIdx.x % mtb_n;
-  const int nt = blockIdx.x / mtb_n;
+  // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the mtb_n blocks that
+  // share one B tile get ids that are equal mod 8 (same XCD, adjacent in dispatch order): the tile crosses the fabric
+  // once instead of mtb_n times (PMC: FETCH_SIZE was 3.4x the algorithmic bytes on the M = 512 layers).
+  const int grp = blockIdx.x / (8 * mtb_n), rem = blockIdx.x - grp * (8 * mtb_n);
+  const int mtb = rem >> 3;
+  const int nt = grp * 8 + (rem & 7);
+  if (nt >= g.NT) return;  // block-uniform (grid is padded to 8 N-tiles)
   const int mt = mtb * 4 + wave;
   const bool mactive = mt < g.MT;
   const int mtc = mactive ? mt : g.MT - 1;
@@ -494,7 +504,7 @@ static void launch_gemm_t(const GemmArgs& g, bool vec_store, bool aligned, hipSt
   const int var = gemm_variant();
   const bool use_dma = aligned && (var == 3 || var == 4 || (var == 0 && g.MT >= 4 && g.KS >= 4));
   if (use_dma) {
-    const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)g.NT);
+    const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
     const bool deep = var == 4;
     const int depth = deep ? 8 : 4;
     const size_t lds = (size_t)(depth + 1) * (4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4;
@@ -518,7 +528,7 @@ static void launch_gemm_t(const GemmArgs& g, bool vec_store, bool aligned, hipSt
   }
   const bool use_lds = var == 2 || (var == 0 && g.MT >= 2 && g.KS >= 2);
   if (use_lds) {
-    const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)g.NT);
+    const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
     if (!aligned)
       hipLaunchKernelGGL((gemm_i8_lds_kernel<MA, OUT, false, false, false>), dim3(blocks), dim3(256), 0, s, g);
     else if (vec_store && mfull)
