@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer timing table to stderr")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1,
                     help="predictors per GPU, each on its own host thread + HIP stream with batch/streams images "
                          "(the reference's one-predictor-per-thread model, cxx_api.h:103-137); kernels of different "
                          "streams overlap, hiding per-launch fill/drain")
@@ -96,7 +96,8 @@ def cpu_baseline(wl, W, seconds):
 def main():
     args = parse()
     # the CPU baseline's OpenMP team = the cores this process may actually use (not every core of the host)
-    os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0))))
+    # (capped at 32: the per-layer GEMMs of one image are too small to feed more threads — 256 threads measured slower)
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(32, len(os.sched_getaffinity(0)))))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge

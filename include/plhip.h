@@ -110,6 +110,19 @@ plhip_status plhip_depthwise_conv_int8(plhip_ctx* ctx, const plhip_conv_desc* d,
                                        const int8_t* w_oihw, const float* scale, const float* bias,
                                        void* y, plhip_out_kind out);
 
+/* ---- fused depthwise 3x3 [int8_out] -> pointwise 1x1 (graph-level fusion) ----
+ * Replaces the instruction pair  depthwise_conv2d[int8_out] ; conv2d 1x1 s1 p0 g1  of the MobileNet programs
+ *  when the depthwise output has no other consumer.  Result is bit-identical to running
+ * plhip_depthwise_conv_int8 (PLHIP_OUT_I8) followed by plhip_conv2d_int8; the int8 intermediate never leaves the CU.
+ * dw: descriptor of the depthwise conv (groups == cin == cout, 3x3, stride 1|2, dilation 1); dw_scale / dw_bias: its
+ * folded int8-out scale / bias; pw_cout, pw_w_packed (from plhip_pack_conv_weights of the 1x1 conv), pw_scale / pw_bias,
+ * pw_act / pw_alpha describe the pointwise conv; y: [n, pw_cout, oh, ow] of kind `out`.
+ * Returns PLHIP_ERR_UNSUPPORTED when the shape is outside the fused path (caller falls back to the two calls). */
+plhip_status plhip_dwpw_fused_int8(plhip_ctx* ctx, const plhip_conv_desc* dw, const int8_t* x, const int8_t* dw_w_oihw,
+                                   const float* dw_scale, const float* dw_bias, int pw_cout, const void* pw_w_packed,
+                                   const float* pw_scale, const float* pw_bias, int pw_act, float pw_alpha, void* y,
+                                   plhip_out_kind out);
+
 /* ---- fc ----
  * Replaces: FcCompute<kInt8,*>::Run (lite/kernels/arm/fc_compute.cc:229-344) -> gemm_s8 / gemv_int8
  * (lite/backends/arm/math/gemm_s8.cc:23-47, gemv_arm_int8.cc:701-760).

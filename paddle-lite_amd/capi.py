@@ -22,7 +22,7 @@ EXPORTS = [
     "plhip_memcpy_d2h", "plhip_memcpy_d2d", "plhip_memset", "plhip_stream_sync", "plhip_event_create",
     "plhip_event_record", "plhip_event_elapsed_ms", "plhip_event_destroy",
     "plhip_conv_packed_weight_bytes", "plhip_pack_conv_weights", "plhip_conv_workspace_bytes",
-    "plhip_conv2d_int8", "plhip_conv_impl_name", "plhip_depthwise_conv_int8",
+    "plhip_conv2d_int8", "plhip_conv_impl_name", "plhip_depthwise_conv_int8", "plhip_dwpw_fused_int8",
     "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
     "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
     "plhip_selftest",
@@ -101,6 +101,7 @@ def load():
     L.plhip_conv_impl_name.argtypes = [C.POINTER(ConvDesc)]
     L.plhip_conv_impl_name.restype = C.c_char_p
     L.plhip_depthwise_conv_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32]
+    L.plhip_dwpw_fused_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, vp, i32]
     L.plhip_fc_packed_weight_bytes.argtypes = [i32, i32]
     L.plhip_fc_packed_weight_bytes.restype = sz
     L.plhip_pack_fc_weights.argtypes = [vp, i32, i32, vp, vp]
@@ -198,6 +199,30 @@ class Context:
             tmp += [dwp] + ([dws] if wsb else [])
         y = self.to_host(dy, (d.n, d.cout, oh, ow), _OUT_DTYPE[out_kind])
         for p in tmp + ([ds] if scale is not None else []) + ([db] if bias is not None else []):
+            self.free(p)
+        return y
+
+    def dwpw_fused(self, d_dw, x, w_dw, s_dw, b_dw, w_pw, s_pw, b_pw, pw_act, pw_alpha, out_kind):
+        """Fused depthwise -> pointwise through the C ABI (host arrays in, host array out)."""
+        oh, ow = out_hw(d_dw)
+        cout = w_pw.shape[0]
+        d_pw = conv_desc(d_dw.n, d_dw.cin, oh, ow, cout, 1, 1, act=pw_act, alpha=pw_alpha)
+        dx = self.to_device(np.ascontiguousarray(x, np.int8))
+        dwd = self.to_device(np.ascontiguousarray(w_dw, np.int8))
+        dsd = self.to_device(np.ascontiguousarray(s_dw, np.float32))
+        dbd = self.to_device(np.ascontiguousarray(b_dw, np.float32)) if b_dw is not None else C.c_void_p()
+        dwp_raw = self.to_device(np.ascontiguousarray(w_pw, np.int8))
+        dwp = self.malloc(self.L.plhip_conv_packed_weight_bytes(C.byref(d_pw)))
+        self.check(self.L.plhip_pack_conv_weights(self.h, C.byref(d_pw), dwp_raw, dwp), "pack")
+        dsp = self.to_device(np.ascontiguousarray(s_pw, np.float32)) if s_pw is not None else C.c_void_p()
+        dbp = self.to_device(np.ascontiguousarray(b_pw, np.float32)) if b_pw is not None else C.c_void_p()
+        esz = 1 if out_kind == OUT_I8 else 4
+        dy = self.malloc(d_dw.n * cout * oh * ow * esz)
+        self.check(self.L.plhip_dwpw_fused_int8(self.h, C.byref(d_dw), dx, dwd, dsd, dbd, cout, dwp, dsp, dbp, pw_act, pw_alpha,
+                                                dy, out_kind), "dwpw_fused")
+        y = self.to_host(dy, (d_dw.n, cout, oh, ow), _OUT_DTYPE[out_kind])
+        for p in [dx, dwd, dsd, dwp_raw, dwp, dy] + ([dbd] if b_dw is not None else []) + ([dsp] if s_pw is not None else []) + \
+                ([dbp] if b_pw is not None else []):
             self.free(p)
         return y
 

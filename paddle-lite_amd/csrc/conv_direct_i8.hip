@@ -350,13 +350,13 @@ __global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, con
     }
     if (qvalid) {
       if (OUT == OUT_I32) {
-        gemm_epilogue<1, OUT, VEC_STORE, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
+        gemm_epilogue<1, OUT, VEC_STORE, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
       } else {
         switch (a.act) {
-          case ACT_RELU: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_RELU>(g, acc, mt, h, b, hw, lsb); break;
-          case ACT_RELU6: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_RELU6>(g, acc, mt, h, b, hw, lsb); break;
-          case ACT_LEAKY: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb); break;
-          default: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb); break;
+          case ACT_RELU: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+          case ACT_RELU6: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+          case ACT_LEAKY: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+          default: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
         }
       }
     }

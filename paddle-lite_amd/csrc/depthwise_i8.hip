@@ -18,6 +18,7 @@
 
 #include "plhip_device.h"
 #include "plhip_kernels.h"
+#include "dw_common.h"
 
 namespace plhip {
 
@@ -221,26 +222,6 @@ __global__ __launch_bounds__(256) void depthwise_i8_kernel(DwArgs a) {
 //   * the 4 sliding windows are cut with v_alignbyte_b32 and hit the packed filter row with v_dot4_i32_i8; each input
 //     row's windows are reused for the (up to) 3 output rows it feeds;
 //   * no LDS, no barrier, no shuffles; image borders are handled by per-lane byte masks (zero padding).
-template <int ACT>
-__device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, float b2, float alpha, float lo2, float hi2) {
-  if (ACT == ACT_RELU || ACT == ACT_RELU6) {
-    uint32_t t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)a[j], s2, b2), lo2, hi2);
-    const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-    return ((p + 0x01010101u) >> 1) & 0x7f7f7f7fu;
-  }
-  int q[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float y2 = __fmaf_rn((float)a[j], s2, b2);
-    if (ACT == ACT_LEAKY) y2 = y2 > 0.f ? y2 : alpha * y2;
-    const int t = (int)__builtin_amdgcn_fmed3f(y2, lo2, hi2);
-    q[j] = (t + 1 + (t >> 31)) >> 1;
-  }
-  return pack4_i8(q[0], q[1], q[2], q[3]);
-}
-
 template <int OUT, int ACT>
 __device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int room, const int (&acc)[4], float s, float bi) {
   if (OUT == OUT_I32) {
@@ -271,46 +252,6 @@ __device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int r
         if (j < room) yp[j] = (int8_t)((pk >> (8 * j)) & 0xff);
     }
   }
-}
-
-// Row fetch, branch free: the row index is clamped (an out-of-image row only zeroes the masks), the column start is
-// clamped for the left border (the missing bytes are shifted in as zeros), and — only in the TAIL instantiation, which
-// the last workgroup alone runs — the address is pulled back so that the load never crosses the end of the tensor.
-template <int ND, bool TAIL>
-__device__ __forceinline__ void dw_load_row(const int8_t* __restrict__ xplane, int ih, int h, int w, int lcol, int sh,
-                                            long plane_room, const uint32_t (&cmask)[ND], uint32_t (&d)[ND]) {
-  const bool rv = ih >= 0 && ih < h;
-  const int ihc = ih < 0 ? 0 : (ih >= h ? h - 1 : ih);
-  int off = ihc * w + lcol;  // byte offset inside the plane
-  int back = 0;
-  if (TAIL) {
-    const long lim = plane_room - 4 * ND;  // last offset from which 4*ND bytes are still inside the tensor
-    if (off > lim) {
-      back = off - (int)(lim < 0 ? 0 : lim);
-      off -= back;
-    }
-  }
-  __builtin_memcpy(d, xplane + off, 4 * ND);
-  if (TAIL && back) {  // bytes were fetched `back` too early: shift them down, zeros come in from the top
-    const int s8 = 8 * (back & 3), dw = back >> 2;
-    uint32_t t[ND];
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      const uint32_t lo = (i + dw < ND) ? d[(i + dw < ND) ? i + dw : 0] : 0u;
-      const uint32_t hi = (i + dw + 1 < ND) ? d[(i + dw + 1 < ND) ? i + dw + 1 : 0] : 0u;
-      t[i] = s8 ? ((lo >> s8) | (hi << (32 - s8))) : lo;
-    }
-#pragma unroll
-    for (int i = 0; i < ND; ++i) d[i] = t[i];
-  }
-  if (sh) {  // left border lane: make room for the zero padding bytes
-    const int s8 = 8 * sh;
-    if (ND == 3) d[ND - 1] = (d[ND - 1] << s8) | (d[ND - 2] >> (32 - s8));
-    d[1] = (d[1] << s8) | (d[0] >> (32 - s8));
-    d[0] = d[0] << s8;
-  }
-#pragma unroll
-  for (int i = 0; i < ND; ++i) d[i] = rv ? (d[i] & cmask[i]) : 0u;
 }
 
 // STAGE (int8 output, narrow planes): PMC showed the 14x14 / 7x7 layers bound by the L2 write-REQUEST rate — a store

@@ -6,6 +6,16 @@
 
 namespace plhip {
 
+// A fragment of tile row-block mt (32-row tiles mt*MA + a), K-step ks: one coalesced 1-KiB load per fragment.
+template <int MA>
+__device__ __forceinline__ void load_a(const int8_t* __restrict__ wp, int mt, int KS, int ks, int lane, v4i (&af)[MA]) {
+#pragma unroll
+  for (int a = 0; a < MA; ++a) {
+    const size_t off = ((size_t)((size_t)(mt * MA + a) * KS + ks) * 64 + lane) * 16;
+    af[a] = *reinterpret_cast<const v4i*>(wp + off);
+  }
+}
+
 // ---- epilogue ----------------------------------------------------------------------------------------------
 // C/D layout of the 32x32 MFMA: col = lane&31 (-> n = 4c+i), row = (r&3) + 8*(r>>2) + 4*(lane>>5).  For register
 // group gq = r>>2 a lane therefore owns 4 CONSECUTIVE rows 8gq + 4h + (0..3): their scales / biases are one 16-byte
@@ -23,8 +33,9 @@ __device__ __forceinline__ float act2(float y2, float alpha) {  // activation on
 
 template <int MA, int OUT, bool VEC_STORE, bool MFULL, int ACT>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&acc)[MA][4], int mt, int h, int b, int hw,
-                                              const float* lsb) {
-  const int hwy_room = g.HWY - hw;  // columns hw+i with i < hwy_room are real outputs (im2col pitch pad)
+                                              const float* lsb, int hwy_room) {
+  // hwy_room: columns hw+i with i < hwy_room are real outputs (GEMM: HWY - hw, the im2col pitch pad; fused dw+pw: the
+  // columns left in the output row)
   const size_t ybase = (size_t)b * g.y_bstride + hw;
   const float hi2 = ACT == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
   const float lo2 = (ACT == ACT_RELU || ACT == ACT_RELU6) ? 0.f : -254.f;
@@ -54,11 +65,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
           if (VEC_STORE) {
             v4i v = {v0, v1, v2, v3};
             *reinterpret_cast<v4i*>(yp) = v;
+          } else if (hwy_room >= 4) {
+            v4i v = {v0, v1, v2, v3};
+            __builtin_memcpy(yp, &v, 16);  // possibly unaligned: fine for global memory
           } else {
             if (0 < hwy_room) yp[0] = v0;
             if (1 < hwy_room) yp[1] = v1;
             if (2 < hwy_room) yp[2] = v2;
-            if (3 < hwy_room) yp[3] = v3;
           }
         } else if (OUT == OUT_F32) {
           const float s = sc[e], bb = bi[e];
@@ -74,11 +87,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
           if (VEC_STORE) {
             v4f v = {f[0], f[1], f[2], f[3]};
             *reinterpret_cast<v4f*>(yp) = v;
+          } else if (hwy_room >= 4) {
+            v4f v = {f[0], f[1], f[2], f[3]};
+            __builtin_memcpy(yp, &v, 16);
           } else {
             if (0 < hwy_room) yp[0] = f[0];
             if (1 < hwy_room) yp[1] = f[1];
             if (2 < hwy_room) yp[2] = f[2];
-            if (3 < hwy_room) yp[3] = f[3];
           }
         } else {
           const float s2 = sc[e] + sc[e], b2 = bi[e] + bi[e];
@@ -104,6 +119,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
           int8_t* yp = reinterpret_cast<int8_t*>(g.y) + yoff;
           if (VEC_STORE) {
             *reinterpret_cast<uint32_t*>(yp) = packed;
+          } else if (hwy_room >= 4) {
+            __builtin_memcpy(yp, &packed, 4);  // possibly unaligned: fine for global memory
           } else {
             if (0 < hwy_room) yp[0] = (int8_t)(packed & 0xff);
             if (1 < hwy_room) yp[1] = (int8_t)((packed >> 8) & 0xff);

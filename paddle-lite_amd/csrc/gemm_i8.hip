@@ -31,15 +31,6 @@
 
 namespace plhip {
 
-template <int MA>
-__device__ __forceinline__ void load_a(const int8_t* __restrict__ wp, int mt, int KS, int ks, int lane, v4i (&af)[MA]) {
-#pragma unroll
-  for (int a = 0; a < MA; ++a) {
-    const size_t off = ((size_t)((size_t)(mt * MA + a) * KS + ks) * 64 + lane) * 16;
-    af[a] = *reinterpret_cast<const v4i*>(wp + off);
-  }
-}
-
 // ALIGNED: every row dword is 4-byte aligned and inside the tensor.  Otherwise (dense slabs with HW % 4 != 0, e.g. the
 // 7x7 layers, or a misaligned base) the dwords are read unaligned — legal for global memory on gfx950 — and the one
 // dword that would cross the end of the tensor is assembled bytewise.  Columns >= HW of a 4-column group then hold
@@ -130,14 +121,14 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
   if (!nvalid || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
-    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
+    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
     return;
   }
   switch (g.act) {  // wave-uniform: one straight-line epilogue per activation
-    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb); break;
-    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb); break;
-    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb); break;
-    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
   }
 }
 
@@ -250,14 +241,14 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
   if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
   if (!nvalid || !mactive || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
-    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
+    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
     return;
   }
   switch (g.act) {
-    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb); break;
-    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb); break;
-    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb); break;
-    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
   }
 }
 
@@ -423,14 +414,14 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
   if (!nvalid || !mactive || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
-    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb);
+    gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
     return;
   }
   switch (g.act) {
-    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb); break;
-    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb); break;
-    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb); break;
-    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb); break;
+    case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+    default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
   }
 }
 

@@ -51,6 +51,21 @@ struct DwArgs {
   float alpha;
 };
 
+// fused depthwise 3x3 (int8 out) -> pointwise 1x1
+struct FusedArgs {
+  const int8_t* x;        // [n, C, h, w]
+  const int8_t* dw_w;     // [C, 1, 3, 3]
+  const float* dw_scale;  // folded depthwise scale / bias (int8-out folding), per channel
+  const float* dw_bias;   // or nullptr
+  int dw_act;
+  float dw_alpha;
+  int n, C, h, w, oh, ow, pt, pl, stride;
+  int R;                  // output rows (of the flattened batch x OH space) per tile, set by the launcher
+  GemmArgs pw;            // wp, y, scale, bias, M, KS, HWY (= oh*ow), y_bstride, act, alpha
+};
+bool fused_dwpw_supported(int C, int kh, int kw, int sh, int sw, int dh, int dw, int pl, int ow);
+void launch_fused_dwpw(const FusedArgs& a, int out, hipStream_t s);
+
 void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);
 void launch_pack_weights(const int8_t* w, int8_t* wp, int G, int Mg, int Kg, int MT32, int KS, hipStream_t s);
 void launch_im2col(const Im2colArgs& a, hipStream_t s);

@@ -1,0 +1,65 @@
+"""GPU: fused depthwise3x3 -> pointwise1x1 (plhip_dwpw_fused_int8) must be bit-identical to the two-kernel path and to
+the oracle's two-stage computation (depthwise int8_out, then 1x1 conv)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(ctx, capi, plref, rng, n, c, h, w, stride, pad, m, dw_act, pw_act, int8_out, pw_alpha=0.0, dw_alpha=0.0):
+    x = rng.integers(-127, 128, (n, c, h, w)).astype(np.int8)
+    w_dw = rng.integers(-127, 128, (c, 1, 3, 3)).astype(np.int8)
+    w_pw = rng.integers(-127, 128, (m, c, 1, 1)).astype(np.int8)
+    b_dw = rng.uniform(-1, 1, c).astype(np.float32)
+    b_pw = rng.uniform(-1, 1, m).astype(np.float32)
+    ws_dw = ((1 + np.arange(c) % 7) / 127.0 / 4.0).astype(np.float32)
+    ws_pw = ((1 + np.arange(m) % 5) / 127.0 / 4.0).astype(np.float32)
+    in_s, mid_s = 1 / 127.0, (9 / 127.0 if dw_act != 2 else dw_alpha / 127.0)
+    out_s = c / 127.0 / 8 if pw_act != 2 else pw_alpha / 127.0
+    sd = plref.shape(n, c, h, w, c, 3, 3, pad, (stride, stride), (1, 1), c)
+    oh, ow = plref.out_dims(sd)
+    # oracle, stage 1: depthwise int8_out
+    s1, b1, a1 = plref.fold_scales(1, in_s, ws_dw, mid_s, b_dw, c, dw_act, dw_alpha)
+    d_ref, _ = plref.conv2d(sd, x, w_dw, b_dw, in_s, ws_dw, mid_s, dw_act, dw_alpha, True)
+    # stage 2: pointwise
+    sp = plref.shape(n, c, oh, ow, m, 1, 1, (0, 0, 0, 0), (1, 1), (1, 1), 1)
+    y_ref, acc_ref = plref.conv2d(sp, d_ref, w_pw, b_pw, mid_s, ws_pw, out_s, pw_act, pw_alpha, int8_out)
+    s2, b2, a2 = plref.fold_scales(int(int8_out), mid_s, ws_pw, out_s, b_pw, m, pw_act, pw_alpha)
+    d_dw = capi.conv_desc(n, c, h, w, c, 3, 3, pad, (stride, stride), (1, 1), c, dw_act, a1)
+    acc = ctx.dwpw_fused(d_dw, x, w_dw, s1, b1, w_pw, None, None, pw_act, a2, capi.OUT_I32)
+    assert np.array_equal(acc, acc_ref), "fused int32 accumulators differ"
+    y = ctx.dwpw_fused(d_dw, x, w_dw, s1, b1, w_pw, s2, b2, pw_act, a2, capi.OUT_I8 if int8_out else capi.OUT_F32)
+    if int8_out:
+        assert np.array_equal(y, y_ref), "fused int8 output differs"
+    else:
+        np.testing.assert_allclose(y, y_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
+    rng = np.random.default_rng(300)
+    capi = pkg.capi
+    cases = [
+        # n, c, h, w, stride, pad(t,b,l,r), m, dw_act, pw_act, int8_out
+        (2, 32, 16, 16, 1, (1, 1, 1, 1), 64, 1, 1, True),
+        (2, 64, 16, 16, 2, (1, 1, 1, 1), 128, 1, 1, True),
+        (3, 128, 14, 14, 1, (1, 1, 1, 1), 256, 1, 1, True),     # OW % 4 != 0: padded quads, partial stores
+        (2, 96, 7, 7, 1, (1, 1, 1, 1), 160, 1, 1, False),       # 7x7, fp32 out, M tail, K = 96
+        (1, 40, 9, 13, 2, (0, 1, 1, 0), 33, 0, 4, True),        # rectangular, asymmetric pads, K % 32 != 0, leaky
+        (2, 512, 14, 14, 1, (1, 1, 1, 1), 512, 1, 1, True),     # MobileNet dw8 / pw8
+        (5, 256, 28, 28, 2, (1, 1, 1, 1), 512, 2, 2, True),     # relu6 both
+        (1, 1024, 7, 7, 1, (1, 1, 1, 1), 1024, 1, 1, False),    # dw14 / pw14, 128 KiB of fragments
+        (1, 16, 112, 112, 1, (1, 1, 1, 1), 24, 1, 0, True),     # one row per tile, 4 dead quads
+    ]
+    for (n, c, h, w, st, pad, m, da, pa, i8) in cases:
+        _case(gpu_ctx, capi, plref, rng, n, c, h, w, st, pad, m, da, pa, i8, pw_alpha=(6.0 if pa == 2 else 0.3),
+              dw_alpha=(6.0 if da == 2 else 0.0))
+
+
+def test_fused_unsupported_shapes_are_reported(gpu_ctx, pkg):
+    import ctypes as C
+    capi = pkg.capi
+    d = capi.conv_desc(1, 8, 16, 16, 8, 5, 5, (2, 2, 2, 2), (1, 1), (1, 1), 8)  # 5x5 depthwise: not fused
+    z = gpu_ctx.malloc(1 << 16)
+    st = gpu_ctx.L.plhip_dwpw_fused_int8(gpu_ctx.h, C.byref(d), z, z, z, None, 8, z, z, None, 0, 0.0, z, capi.OUT_I8)
+    assert st == -3
+    gpu_ctx.free(z)

@@ -79,6 +79,37 @@ def main():
                 L.plhip_conv_impl_name(C.byref(d)).decode() if g == 1 else "depthwise"), flush=True)
             for q in list(ctx._allocs):
                 ctx.free(q)
+    if args.what in ("fused", "all"):
+        ftot = 0.0
+        with capi.Context(0) as ctx:
+            L = ctx.L
+            layers = wl.mobilenet_v1_layers()
+            for i in range(1, len(layers), 2):
+                (dn, _, c, _, k, s, p, g, hin) = layers[i]
+                (pn, _, _, m, _, _, _, _, hmid) = layers[i + 1]
+                d = capi.conv_desc(B, c, hin, hin, c, 3, 3, (p, p, p, p), (s, s), (1, 1), c, capi.ACT_RELU, 0.0)
+                dp = capi.conv_desc(B, c, hmid, hmid, m, 1, 1, act=capi.ACT_RELU)
+                dx = ctx.to_device(rng.integers(-127, 128, (B, c, hin, hin), dtype=np.int8))
+                dwd = ctx.to_device(rng.integers(-127, 128, (c, 1, 3, 3), dtype=np.int8))
+                dsd = ctx.to_device(np.full(c, 1e-2, np.float32))
+                dwr = ctx.to_device(rng.integers(-127, 128, (m, c, 1, 1), dtype=np.int8))
+                dwp = ctx.malloc(L.plhip_conv_packed_weight_bytes(C.byref(dp)))
+                ctx.check(L.plhip_pack_conv_weights(ctx.h, C.byref(dp), dwr, dwp), "pack")
+                dsp = ctx.to_device(np.full(m, 1e-4, np.float32))
+                out_kind = capi.OUT_F32 if pn == "pw14" else capi.OUT_I8
+                esz = 4 if out_kind == capi.OUT_F32 else 1
+                dy = ctx.malloc(B * m * hmid * hmid * esz)
+                fn = lambda: ctx.check(L.plhip_dwpw_fused_int8(ctx.h, C.byref(d), dx, dwd, dsd, None, m, dwp, dsp, None,
+                                                               capi.ACT_RELU, 0.0, dy, out_kind), "fused")
+                ms = time_op(ctx, fn, args.reps)
+                byts = B * (c * hin * hin + m * hmid * hmid * esz)
+                macs = B * hmid * hmid * (m * c + 9 * c)
+                ftot += ms
+                print("%-4s+%-5s fused %4d->%4d %3dx%-3d s%d  %8.2f us  %7.1f GB/s  %7.1f TOP/s" % (
+                    dn, pn, c, m, hin, hin, s, ms * 1e3, byts / ms / 1e6, 2 * macs / ms / 1e9), flush=True)
+                for q in list(ctx._allocs):
+                    ctx.free(q)
+        print("fused total %.2f us" % (ftot * 1e3))
     print("total %.2f us" % (tot * 1e3))
 
 
