@@ -27,6 +27,8 @@
 
 #include "plhip_device.h"
 #include "plhip_kernels.h"
+#include <type_traits>
+
 #include "gemm_epilogue.h"
 
 namespace plhip {
@@ -253,6 +255,15 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
 }
 
 // =====================================================================================================================
+// ---- diagnostic timeline (PLHIP_GEMM_DEBUG & 32; never set in production): per-wave s_memtime stamps of the LDS-DMA
+// kernel, kept in LDS during the run and flushed to this buffer at the end (plhip_debug_read_stamps reads it).
+constexpr int STAMP_SLOTS = 32;
+__device__ unsigned long long g_stamps[1024 * 4 * STAMP_SLOTS];
+#define PLHIP_STAMP(i)                                                                        \
+  do {                                                                                        \
+    if (diag && lane == 0) lstamp[i] = __builtin_amdgcn_s_memtime();                          \
+  } while (0)
+
 // LDS-DMA ring variant (the fast path for MFMA-heavy layers: M >= 256-ish, K >= 128, 4-byte aligned rows).
 // PMC on the register-staged kernel showed MFMA busy ~13 % per wave and one full memory latency per stage: register
 // staging cannot keep enough K-steps in flight (VGPR-bound), and the in-order vmcnt couples the short A loads to the
@@ -277,7 +288,7 @@ template <int MA, int OUT, bool VEC_STORE, bool MFULL, int GD_D>
 __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(GemmArgs g) {
   constexpr int GD_NS = GD_D + 1;
   constexpr int SLOT = 4096 + 4 * MA * 1024;
-  constexpr int PER = 4 + MA;  // DMA instructions per wave per K-step
+  constexpr int PER = 1 + MA;  // DMA instructions per wave per K-step
   extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // GD_NS * SLOT ring + 4 waves x scale/bias (ONE LDS object)
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -295,32 +306,66 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   const bool mactive = mt < g.MT;
   const int mtc = mactive ? mt : g.MT - 1;
   const int c = lane & 31, h = lane >> 5;
-  const int ntot = g.NB * g.HWX;
-
+  // Column space: every image's HWX columns are padded to HWP = roundup(HWX, 16) so that the B tile moves as 16-byte
+  // pieces (ONE 1-KiB LDS-DMA instruction per wave and K-step instead of four 256-byte ones: the loop was bound by the
+  // number of vector-memory instructions, not by bytes).  The last piece of an image is END-aligned (source columns
+  // HWX-16 .. HWX-1), so nothing is read outside the plane; its first 16-r columns duplicate earlier ones and are
+  // never stored (r = HWX % 16; HWX % 4 == 0 keeps each lane's 4 columns all-real or all-duplicate).
+  const int HWP = (g.HWX + 15) & ~15, full16 = g.HWX & ~15, rem16 = g.HWX & 15;
   int n4 = nt * 128 + 4 * c;
-  const bool nvalid = n4 < ntot;
-  if (!nvalid) n4 = 0;
-  const int b = n4 / g.HWX;
-  const int hw = n4 - b * g.HWX;
-  const int8_t* xb = g.x + (size_t)b * g.x_bstride + hw;
+  int b = n4 / HWP;
+  int j = n4 - b * HWP;
+  const bool nvalid = b < g.NB && (j < full16 || j >= HWP - rem16);
+  if (!nvalid) { b = 0; j = 0; }
+  const int hw = j < full16 ? j : j + rem16 - 16;
+  // my 16-byte piece of the B tile: row 8*wave + lane/8 of the K-step, columns 16*(lane&7) ...
+  const int prow = 8 * wave + (lane >> 3);
+  const int8_t* xb;
+  {
+    const int np = nt * 128 + 16 * (lane & 7);
+    int pb = np / HWP;
+    int pj = np - pb * HWP;
+    if (pb >= g.NB) { pb = 0; pj = 0; }
+    xb = g.x + (size_t)pb * g.x_bstride + (pj < full16 ? pj : g.HWX - 16);
+  }
   const int8_t* ab = g.wp + (size_t)mtc * MA * g.KS * 1024 + lane * 16;
   const int KS = g.KS;
   float* lsb = reinterpret_cast<float*>(ring + GD_NS * SLOT) + wave * 2 * MA * 32;
+  const bool diag = (g.dbg & 32) != 0;
+  unsigned long long* lstamp = reinterpret_cast<unsigned long long*>(ring + GD_NS * SLOT + 4 * 2 * MA * 32 * 4) + wave * STAMP_SLOTS;
+  if (diag && lane == 0) {
+    lstamp[0] = __builtin_amdgcn_s_memrealtime();
+    lstamp[1] = __builtin_amdgcn_s_memtime();
+    lstamp[2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  }
 
   auto issue = [&](int ks, int slot) {
     uint8_t* sb = ring + slot * SLOT;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = 8 * wave + 2 * q;  // rows row, row+1 of the K-step: lanes 0-31 / 32-63
-      int k = ks * 32 + row + h;
-      k = k < g.K ? k : g.K - 1;
-      __builtin_amdgcn_global_load_lds((glb_ptr)(xb + (size_t)k * g.XP), (lds_ptr)(sb + row * 128), 4, 0, 0);
-    }
+    int k = ks * 32 + prow;
+    k = k < g.K ? k : g.K - 1;  // rows past K meet zero-padded weights
+    __builtin_amdgcn_global_load_lds((glb_ptr)(xb + (size_t)k * g.XP), (lds_ptr)(sb + wave * 1024), 16, 0, 0);
 #pragma unroll
     for (int a = 0; a < MA; ++a)
       __builtin_amdgcn_global_load_lds((glb_ptr)(ab + ((size_t)a * KS + ks) * 1024), (lds_ptr)(sb + 4096 + (wave * MA + a) * 1024), 16, 0, 0);
   };
 
+  // ---- pipeline ----
+  // Ring of GD_NS = GD_D + 1 slots, AHEAD = GD_D K-steps in flight.  Iteration ks:
+  //   wait(my pieces of K-step ks+1 landed) ; barrier ; issue the LDS reads of K-step ks+1 (raw B rows + my A fragments) ;
+  //   MFMAs of K-step ks from registers, and IN THEIR SHADOW: the DMA of K-step ks+AHEAD (its slot held K-step ks-1,
+  //   which every wave finished reading before this barrier), then the 32 v_perm that turn the raw rows of ks+1 into B
+  //   fragments.  An in-order wave stalls at the first consumer of an LDS read, so the first MFMAs carry the DMA issue
+  //   and the transposes start only after them (timeline stamps: the former order -- waitcnt lgkmcnt(0) in front of the
+  //   first MFMA, DMA issue and a run-time vmcnt switch in front of the barrier -- cost ~1190 cycles per K-step for
+  //   256 cycles of MFMA).
+  constexpr int AHEAD = GD_D;
+  // prologue: K-steps 0 .. AHEAD-1 in flight (the launcher guarantees KS >= AHEAD); the accumulators are zeroed
+  // behind the issue, while the first bytes travel
+#pragma unroll
+  for (int p = 0; p < AHEAD; ++p) issue(p, p);
+  float my_s = 1.f, my_b = 0.f;
+  if (OUT != OUT_I32) load_scale_bias<MA>(g, mtc, lane, my_s, my_b);  // 2 more vmcnt entries, younger than the prologue DMA
+  __builtin_amdgcn_sched_barrier(0);
   v16i acc[MA][4];
 #pragma unroll
   for (int a = 0; a < MA; ++a)
@@ -329,27 +374,6 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][i][r] = 0;
 
-  // prologue: D-1 K-steps in flight
-#pragma unroll
-  for (int p = 0; p < GD_D - 1; ++p)
-    if (p < KS) issue(p, p);
-  // scale / bias: plain loads behind the prologue DMA; they reach LDS after the K loop
-  float my_s = 1.f, my_b = 0.f;
-  if (OUT != OUT_I32) load_scale_bias<MA>(g, mtc, lane, my_s, my_b);
-
-  // Software pipeline inside the wave: while the MFMAs of K-step ks run on the matrix pipe, the raw rows of K-step
-  // ks+1 are read from LDS and transposed on the VALU (independent instruction streams the scheduler interleaves).
-  auto wait_landed = [&](int younger) {  // my DMA share of a K-step has landed once <= `younger` later K-steps are pending
-    switch (younger) {                   // wave-uniform
-      case 0: wait_vmcnt<0>(); break;
-      case 1: wait_vmcnt<1 * PER>(); break;
-      case 2: wait_vmcnt<2 * PER>(); break;
-      case 3: wait_vmcnt<(GD_D > 3 ? 3 : 2) * PER>(); break;
-      case 4: wait_vmcnt<(GD_D > 4 ? 4 : 2) * PER>(); break;
-      case 5: wait_vmcnt<(GD_D > 5 ? 5 : 2) * PER>(); break;
-      default: wait_vmcnt<(GD_D > 6 ? 6 : 2) * PER>(); break;
-    }
-  };
   auto read_slot = [&](int slot, uint32_t (&raw)[16], v4i (&af)[MA]) {
     const uint8_t* sb = ring + slot * SLOT;
 #pragma unroll
@@ -369,48 +393,260 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
     }
   };
 
+  PLHIP_STAMP(3);
   uint32_t raw[16];
   v4i af_cur[MA], af_nxt[MA], bf_cur[4], bf_nxt[4];
-  {  // K-step 0 into registers
-    const int pend = KS - 1 < GD_D - 2 ? KS - 1 : GD_D - 2;
-    wait_landed(pend < 0 ? 0 : pend);
-    __builtin_amdgcn_s_barrier();
-    read_slot(0, raw, af_cur);
-    transpose(raw, bf_cur);
-  }
-  int slot_nxt = 1, islot = GD_D - 1;
-  const int kend = (g.dbg & 2) ? 0 : KS;
-  for (int ks = 0; ks < kend; ++ks) {
-    if (ks + GD_D - 1 < KS) issue(ks + GD_D - 1, islot);
-    islot = islot + 1 == GD_NS ? 0 : islot + 1;
-    const bool has_next = ks + 1 < KS;
-    if (has_next) {
-      // K-steps ks+2 .. min(ks+D-1, KS-1) of mine may still be in flight
-      const int last = ks + GD_D - 1 < KS - 1 ? ks + GD_D - 1 : KS - 1;
-      wait_landed(last - (ks + 1));
-      __builtin_amdgcn_s_barrier();  // slot ks+1 complete for everyone; slot ks-1 (refilled next) no longer read by anyone
-      read_slot(slot_nxt, raw, af_nxt);
-      slot_nxt = slot_nxt + 1 == GD_NS ? 0 : slot_nxt + 1;
+  // K-step 0 into registers: AHEAD-1 younger K-steps of PER pieces each, plus the scale / bias loads
+  wait_vmcnt<(AHEAD - 1) * PER + (OUT != OUT_I32 ? 2 : 0)>();
+  __builtin_amdgcn_s_barrier();
+  read_slot(0, raw, af_cur);
+  transpose(raw, bf_cur);
+
+  // one iteration; YOUNGER = my K-steps issued after ks+1 that may still be in flight at the wait, ISSUE / NEXT: whether
+  // K-step ks+AHEAD / ks+1 exists (compile-time in the steady state and in the peeled tail)
+  int rslot = 1, islot = AHEAD % GD_NS;
+  auto step = [&](int ks, auto younger_c, auto issue_c, auto next_c) {
+    constexpr int YOUNGER = decltype(younger_c)::value;
+    constexpr bool ISSUE = decltype(issue_c)::value;
+    constexpr bool NEXT = decltype(next_c)::value;
+    if (ks < STAMP_SLOTS - 8) PLHIP_STAMP(4 + ks);
+    if (NEXT) {
+      wait_vmcnt<YOUNGER * PER>();
+      __builtin_amdgcn_s_barrier();  // K-step ks+1 complete for everyone; nobody reads K-step ks-1's slot any more
+      read_slot(rslot, raw, af_nxt);
+      rslot = rslot + 1 == GD_NS ? 0 : rslot + 1;
     }
-    // One basic block: 4*MA MFMAs of K-step ks and the 32 v_perm of K-step ks+1, interleaved by the scheduler hints
-    // below (an in-order wave cannot reach VALU work placed behind a queue of MFMAs).  Waves without rows (M tail)
-    // run the MFMAs on clamped tiles and never store; on the last K-step the transposes work on stale registers.
+    if (ISSUE) {
+      issue(ks + AHEAD, islot);
+      islot = islot + 1 == GD_NS ? 0 : islot + 1;
+    }
 #pragma unroll
     for (int a = 0; a < MA; ++a)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur[a], bf_cur[i], acc[a][i], 0, 0, 0);
-    transpose(raw, bf_nxt);
+    if (NEXT) transpose(raw, bf_nxt);
+    // schedule: [MFMA + one DMA piece] x PER, then the remaining MFMAs share the transposes
+    constexpr int NM = 4 * MA;
 #pragma unroll
-    for (int q = 0; q < 4 * MA; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 32 / (4 * MA), 0);  // its share of the VALU transposes
+    for (int q = 0; q < PER; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (ISSUE) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // address arithmetic of the piece
+      if (ISSUE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bf_cur[i] = bf_nxt[i];
+    for (int q = PER; q < NM; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, (32 + NM - PER - 1) / (NM - PER), 0);
+    }
+    if (NEXT) {
 #pragma unroll
-    for (int a = 0; a < MA; ++a) af_cur[a] = af_nxt[a];
+      for (int i = 0; i < 4; ++i) bf_cur[i] = bf_nxt[i];
+#pragma unroll
+      for (int a = 0; a < MA; ++a) af_cur[a] = af_nxt[a];
+    }
+  };
+  using std::integral_constant;
+  const int kmain = (g.dbg & 2) ? 0 : KS - AHEAD;
+  for (int ks = 0; ks < kmain; ++ks)
+    step(ks, integral_constant<int, AHEAD - 2>{}, integral_constant<bool, true>{}, integral_constant<bool, true>{});
+  if (!(g.dbg & 2)) {
+    // peeled tail: K-steps KS-AHEAD .. KS-1, nothing left to issue, the in-flight count shrinks
+    static_assert(AHEAD >= 2 && AHEAD <= 8, "tail is written for 2..8 K-steps ahead");
+    int ks = KS - AHEAD;
+#define PLHIP_TAIL(T)                                                                                              \
+  if (AHEAD - 1 > T) {                                                                                             \
+    step(ks, integral_constant<int, (AHEAD - 2 - T > 0 ? AHEAD - 2 - T : 0)>{}, integral_constant<bool, false>{},  \
+         integral_constant<bool, true>{});                                                                         \
+    ++ks;                                                                                                          \
+  }
+    PLHIP_TAIL(0) PLHIP_TAIL(1) PLHIP_TAIL(2) PLHIP_TAIL(3) PLHIP_TAIL(4) PLHIP_TAIL(5) PLHIP_TAIL(6)
+#undef PLHIP_TAIL
+    step(ks, integral_constant<int, 0>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
   }
 
+  if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
+  PLHIP_STAMP(STAMP_SLOTS - 4);
+  if (nvalid && mactive && !(g.dbg & 1)) {
+    if (OUT == OUT_I32) {
+      gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
+    } else {
+      switch (g.act) {
+        case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+        case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+        case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+        default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+      }
+    }
+  }
+  if (diag) {  // wave-uniform
+    PLHIP_STAMP(STAMP_SLOTS - 3);  // epilogue instructions issued
+    wait_vmcnt<0>();
+    if (lane == 0) {
+      lstamp[STAMP_SLOTS - 2] = __builtin_amdgcn_s_memtime();  // stores acknowledged
+      lstamp[STAMP_SLOTS - 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (blockIdx.x < 1024 && lane < STAMP_SLOTS) g_stamps[((size_t)blockIdx.x * 4 + wave) * STAMP_SLOTS + lane] = lstamp[lane];
+  }
+}
+
+// =====================================================================================================================
+// Wave-specialised variant (producer / consumer) for the MFMA-heavy layers.
+// PMC + ablation on the ring kernel: per K-step every wave ran the chain  barrier -> 18 LDS reads -> 32 v_perm -> 8 MFMA,
+// and with <= 2 waves per SIMD nothing overlapped it (MFMA busy 13 %); a deeper ring changed nothing.  Here the roles are
+// split so that the matrix pipes only ever see ds_read_b128 + MFMA:
+//   * waves 4,5 = PRODUCERS.  Producer p owns k-rows {8p..8p+7, 16+8p..16+8p+7} of every K-step: it fetches them by
+//     LDS-DMA into a PRIVATE ring (5 K-steps in flight, counted vmcnt, no cross-wave dependency on raw data), reads
+//     them back, transposes (16 v_perm) and writes its 8-byte half of the four B fragments into the shared, double
+//     buffered fragment area;
+//   * waves 0-3 = CONSUMERS (64 x 128 outputs each): 4 ds_read_b128 for B, A fragments straight from L2 through a
+//     4-deep register ring (their only vector-memory traffic, so the in-order vmcnt never couples to anything slow),
+//     8 MFMAs per K-step;
+//   * one s_barrier per K-step hands fragment buffer (ks+1)&1 to the consumers and buffer ks&1 back to the producers.
+#define WS_D 5   // K-steps a producer keeps in flight
+#define WS_NS 6  // slots of its private raw ring
+
+template <int OUT, bool VEC_STORE, bool MFULL>
+__global__ __launch_bounds__(384, 2) void gemm_i8_ws_kernel(GemmArgs g) {
+  constexpr int MA = 2;
+  // ONE LDS object: [2 fragment buffers x 4 KiB][2 producers x WS_NS x 2 KiB raw rings][4 consumers x scale/bias]
+  __shared__ __attribute__((aligned(16))) uint8_t sm[2 * 4096 + 2 * WS_NS * 2048 + 4 * 2 * MA * 32 * 4];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mtb_n = (g.MT + 3) >> 2;
+  const int grp = blockIdx.x / (8 * mtb_n), rem = blockIdx.x - grp * (8 * mtb_n);
+  const int mtb = rem >> 3;
+  const int nt = grp * 8 + (rem & 7);
+  if (nt >= g.NT) return;  // block-uniform
+  const int c = lane & 31, h = lane >> 5;
+  const int ntot = g.NB * g.HWX;
+  int n4 = nt * 128 + 4 * c;
+  const bool nvalid = n4 < ntot;
+  if (!nvalid) n4 = 0;
+  const int b = n4 / g.HWX;
+  const int hw = n4 - b * g.HWX;
+  const int KS = g.KS;
+  v4i* frags = reinterpret_cast<v4i*>(sm);  // [buf][i][lane]
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producer
+    const int p = wave - 4;
+    uint8_t* ring = sm + 2 * 4096 + p * WS_NS * 2048;
+    const int8_t* xb = g.x + (size_t)b * g.x_bstride + hw;
+    auto issue = [&](int ks, int slot) {
+      uint8_t* sb = ring + slot * 2048;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int lrow = 2 * q;                                   // local rows lrow, lrow+1 (lanes 0-31 / 32-63)
+        const int krow = (q < 4 ? 8 * p : 16 + 8 * p) + 2 * (q & 3);  // k-row inside the K-step
+        int k = ks * 32 + krow + h;
+        k = k < g.K ? k : g.K - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(xb + (size_t)k * g.XP), (lds_ptr)(sb + lrow * 128), 4, 0, 0);
+      }
+    };
+    auto transpose_to = [&](int slot, int buf) {
+      const uint8_t* sb = ring + slot * 2048;
+      uint32_t raw[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const uint32_t*>(sb + (8 * h + j) * 128 + 4 * c);  // k = 16h + 8p + j
+      uint32_t o[2][4];
+      transpose4x4_b8(raw[0], raw[1], raw[2], raw[3], o[0][0], o[0][1], o[0][2], o[0][3]);
+      transpose4x4_b8(raw[4], raw[5], raw[6], raw[7], o[1][0], o[1][1], o[1][2], o[1][3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // dwords 2p, 2p+1 of lane's 16-byte entry of fragment i
+        uint2 v = make_uint2(o[0][i], o[1][i]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(frags + (buf * 4 + i) * 64 + lane) + 8 * p) = v;
+      }
+    };
+    auto wait_landed = [&](int younger) {
+      switch (younger) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<8>(); break;
+        case 2: wait_vmcnt<16>(); break;
+        case 3: wait_vmcnt<24>(); break;
+        default: wait_vmcnt<32>(); break;
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < WS_D; ++t)
+      if (t < KS) issue(t, t);
+    {
+      const int last = WS_D - 1 < KS - 1 ? WS_D - 1 : KS - 1;
+      wait_landed(last);
+      transpose_to(0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int islot = WS_D % WS_NS, rslot = 1;
+    const int KSP = (KS + 3) & ~3;  // same number of hand-over barriers as the consumers
+    for (int ks = 0; ks < KSP; ++ks) {
+      if (ks + WS_D < KS) issue(ks + WS_D, islot);
+      islot = islot + 1 == WS_NS ? 0 : islot + 1;
+      if (ks + 1 < KS && !(g.dbg & 16)) {
+        const int last = ks + WS_D < KS - 1 ? ks + WS_D : KS - 1;
+        wait_landed(last - (ks + 1));
+        transpose_to(rslot, (ks + 1) & 1);
+        rslot = rslot + 1 == WS_NS ? 0 : rslot + 1;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer
+  const int mt = mtb * 4 + wave;
+  const bool mactive = mt < g.MT;
+  const int mtc = mactive ? mt : g.MT - 1;
+  float* lsb = reinterpret_cast<float*>(sm + 2 * 4096 + 2 * WS_NS * 2048) + wave * 2 * MA * 32;
+  v16i acc[MA][4];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][i][r] = 0;
+  v4i a0[MA], a1[MA], a2[MA], a3[MA];
+  auto load_a_c = [&](int ks, v4i (&af)[MA]) {
+    if ((g.dbg & 8) && ks > 1) return;  // timing experiment: no A traffic inside the loop
+    load_a<MA>(g.wp, mtc, KS, ks < KS ? ks : KS - 1, lane, af);
+  };
+  load_a_c(0, a0);
+  load_a_c(1, a1);
+  float my_s = 1.f, my_b = 0.f;
+  if (OUT != OUT_I32) load_scale_bias<MA>(g, mtc, lane, my_s, my_b);
+  auto kstep = [&](int buf, const v4i (&af)[MA]) {
+    v4i bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bf[i] = frags[(buf * 4 + i) * 64 + lane];
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[a], bf[i], acc[a][i], 0, 0, 0);
+  };
+  __builtin_amdgcn_s_barrier();  // fragment buffer 0 is ready
+  // K loop unrolled by 4 so that the A ring uses static register names; every K-step ends with the hand-over barrier.
+  // Both roles run KSP = roundup(KS, 4) rounds (the surplus ones are empty) so that the barrier counts always match.
+  const int KSP = (KS + 3) & ~3;
+  for (int ks0 = 0; ks0 < KSP; ks0 += 4) {
+    load_a_c(ks0 + 2, a2);
+    kstep(0, a0);  // ks0 < KS always
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_a_c(ks0 + 3, a3);
+    if (ks0 + 1 < KS) kstep(1, a1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_a_c(ks0 + 4, a0);
+    if (ks0 + 2 < KS) kstep(0, a2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_a_c(ks0 + 5, a1);
+    if (ks0 + 3 < KS) kstep(1, a3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
   if (!nvalid || !mactive || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
@@ -480,7 +716,12 @@ __global__ void im2col_i8_kernel(Im2colArgs a) {
 }
 
 // ---- host-side launchers (called from plhip_capi.hip) ----
-static int gemm_variant() {  // PLHIP_GEMM_VARIANT: 0 auto, 1 private-tile kernel, 2 register-staged LDS kernel, 3 LDS-DMA ring
+int debug_read_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(unsigned long long) * 1024 * 4 * STAMP_SLOTS) bytes = sizeof(unsigned long long) * 1024 * 4 * STAMP_SLOTS;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+
+static int gemm_variant() {  // PLHIP_GEMM_VARIANT: 0 auto, 1 private-tile kernel, 2 register-staged LDS kernel, 3 LDS-DMA ring, 4 deep ring, 5 wave-specialised
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("PLHIP_GEMM_VARIANT");
@@ -490,15 +731,28 @@ static int gemm_variant() {  // PLHIP_GEMM_VARIANT: 0 auto, 1 private-tile kerne
 }
 
 template <int MA, int OUT>
-static void launch_gemm_t(const GemmArgs& g, bool vec_store, bool aligned, hipStream_t s) {
+static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hipStream_t s) {
+  GemmArgs g = g_in;
   const bool mfull = g.M % (32 * MA) == 0;
   const int var = gemm_variant();
-  const bool use_dma = aligned && (var == 3 || var == 4 || (var == 0 && g.MT >= 4 && g.KS >= 4));
+  const bool use_ws = MA == 2 && aligned && var == 5;  // experiment, opt-in: slower than the ring
+  if (use_ws) {
+    const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
+    if (vec_store && mfull)
+      hipLaunchKernelGGL((gemm_i8_ws_kernel<OUT, true, true>), dim3(blocks), dim3(384), 0, s, g);
+    else if (vec_store)
+      hipLaunchKernelGGL((gemm_i8_ws_kernel<OUT, true, false>), dim3(blocks), dim3(384), 0, s, g);
+    else
+      hipLaunchKernelGGL((gemm_i8_ws_kernel<OUT, false, false>), dim3(blocks), dim3(384), 0, s, g);
+    return;
+  }
+  const bool use_dma = aligned && g.HWX >= 16 && g.KS >= (var == 4 ? 8 : 4) && (var == 3 || var == 4 || (var == 0 && g.MT >= 4));
   if (use_dma) {
+    g.NT = (int)(((long)g.NB * ((g.HWX + 15) & ~15) + 127) / 128);  // 16-byte padded column space of this kernel
     const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
     const bool deep = var == 4;
     const int depth = deep ? 8 : 4;
-    const size_t lds = (size_t)(depth + 1) * (4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4;
+    const size_t lds = (size_t)(depth + 1) * (4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4 + 4 * STAMP_SLOTS * 8;
 #define PLHIP_LAUNCH_DMA(VS, MF, DD)                                                                              \
   do {                                                                                                            \
     auto kfn = gemm_i8_dma_kernel<MA, OUT, VS, MF, DD>;                                                           \
