@@ -14,6 +14,7 @@
 #include "plhip_device.h"
 #include "plhip_kernels.h"
 #include "gemm_epilogue.h"
+#include "dw_common.h"
 
 namespace plhip {
 
@@ -215,53 +216,33 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(DirectS2Args a) {
 }
 
 // =====================================================================================================================
-// MFMA form of the stem (Cin*9 <= 32, OW % 4 == 0): PMC on the dot4 kernel showed ~2900 VALU per wave, 22 per output,
-// most of them the 9 v_dot4 per output.  Here the 27 taps become ONE K-step of v_mfma_i32_32x32x32_i8: the row windows
-// are gathered exactly as above, but instead of multiplying them they are re-packed (one v_perm per operand dword) into
-// the MFMA B fragment, k = ci*9 + r*3 + q.  Lane (c, h): c = quad (4 consecutive ox, one per MFMA i), h = k half.  The
-// 32 couts of a tile are the MFMA rows; the epilogue is the GEMM one (4 consecutive ox per lane -> one dword store).
-template <int BASE>
-__device__ __forceinline__ uint32_t ds2_kdword(const uint32_t (&w)[DS2_MAXCIN * 3], int K) {
-  // operand bytes k = BASE .. BASE+3 ; byte k lives in window k/3, position k%3
-  constexpr int cr0 = BASE / 3;
-  uint32_t sel = 0;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int k = BASE + t;
-    const int cr = k / 3, q = k - 3 * cr;
-    const uint32_t sb = (k < K && cr < DS2_MAXCIN * 3) ? (uint32_t)(q + (cr == cr0 ? 0 : 4)) : 0x0cu;  // 0x0c -> constant 0
-    sel |= sb << (8 * t);
-  }
-  const uint32_t lo = w[cr0 < DS2_MAXCIN * 3 ? cr0 : 0];
-  const uint32_t hi = w[cr0 + 1 < DS2_MAXCIN * 3 ? cr0 + 1 : 0];
-  return __builtin_amdgcn_perm(hi, lo, sel);
-}
-
-template <int OUT, bool VEC_STORE>
-__global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, const int8_t* __restrict__ afrag) {
-  __shared__ __attribute__((aligned(16))) float lsb_all[4][64];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// MFMA form of the stem (Cin*9 <= 27, OW % 4 == 0).  The 27 taps are ONE K-step of v_mfma_i32_32x32x32_i8.
+// Lane (c, h): c = quad (4 consecutive ox, one per MFMA i), h = k half.  The k order is free as long as the packed A
+// fragments agree, so it is chosen to give both halves the SAME structure: half h owns the row windows
+// cr = 5h .. 5h+4  (cr = ci*3 + filter row; windows >= 3*Cin do not exist and read as zero), 3 taps each:
+//     operand bytes = (L0.0 L0.1 L0.2 L1.0 | L1.1 L1.2 L2.0 L2.1 | L2.2 L3.0 L3.1 L3.2 | L4.0 L4.1 L4.2 0).
+// A lane therefore fetches 5 rows (not 9), and builds each operand with 3 v_perm + 1 v_and using constant selectors.
+// PMC on the previous form (both halves fetched all 9 windows through the guarded general fetch, 64-bit index math):
+// 1057 VALU per wave against ~300 for the requantisation of its 4096 outputs -- the stem was VALU-bound at 2.5x its
+// HBM time.  The 32 couts of a tile are the MFMA rows; the epilogue is the GEMM one (4 consecutive ox per lane -> one
+// dword store).  The first and the last workgroup run the guarded fetch (a window may start one byte before / end a
+// few bytes after the tensor); all others read the window from its true start column and mask.
+template <int OUT, bool MFULL, bool GUARD>
+__device__ __forceinline__ void stem_mfma_body(const DirectS2Args& a, const int8_t* __restrict__ afrag, float* lsb, int lane,
+                                               int wave) {
+  // grid = (quad tiles of a row, groups of 4 output rows, images): the image, the output row and with them every row
+  // offset / validity are wave-uniform (SALU); only the quad index is per lane.  No integer division anywhere.
   const int c = lane & 31, h = lane >> 5;
   const int owq = a.ow >> 2;  // OW % 4 == 0 here
-  const long total = (long)a.n * a.oh * owq;
-  const long wtile = (long)blockIdx.x * 4 + wave;
-  if (wtile * 32 >= total) return;
-  long quad = wtile * 32 + c;
-  const bool qvalid = quad < total;
-  if (!qvalid) quad = total - 1;
-  const int xq = (int)(quad % owq);
-  const long t = quad / owq;
-  const int oy = (int)(t % a.oh);
-  const int b = (int)(t / a.oh);
+  const int b = blockIdx.z;
+  const int oy = blockIdx.y * 4 + wave;
+  if (oy >= a.oh) return;  // wave-uniform; no barrier in this kernel
+  int xq = blockIdx.x * 32 + c;
+  const bool qvalid = xq < owq;
+  if (!qvalid) xq = owq - 1;
   const int start = 8 * xq - a.pl;
-  const int sh = start < 0 ? -start : 0;
-  int lcol = start + sh;
-  if (lcol > a.w - 1) lcol = a.w - 1;
-  const long tensor_bytes = (long)a.n * a.cin * a.h * a.w;
-  const int K = a.cin * 9;
+  const int ncr = a.cin * 3;
 
-  // everything that does not depend on the image goes first, so that its latency overlaps the input loads
   GemmArgs g;
   g.y = a.y;
   g.scale = a.scale;
@@ -271,7 +252,6 @@ __global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, con
   g.y_bstride = (size_t)a.cout * a.oh * a.ow;
   g.act = a.act;
   g.alpha = a.alpha;
-  float* lsb = lsb_all[wave];
   const v4i af0 = *reinterpret_cast<const v4i*>(afrag + (size_t)lane * 16);
   if (OUT != OUT_I32) stage_scale_bias<1>(g, 0, lane, lsb);
 
@@ -286,51 +266,53 @@ __global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, con
     }
     cmask[d] = m;
   }
-  // row windows, as in the dot4 kernel (both k-halves of a column need all of them for the re-pack)
-  uint32_t win[4][DS2_MAXCIN * 3];  // [j][cr]
+  const int sh = start < 0 ? -start : 0;  // GUARD only
+  int lcol = start + sh;
+  if (lcol > a.w - 1) lcol = a.w - 1;
+  const int img_base = b * a.cin * a.h * a.w;  // tensor < 2^31 bytes (host check)
+  const long tensor_bytes = (long)a.n * a.cin * a.h * a.w;
+
+  uint32_t win[4][5];  // [j][L]
 #pragma unroll
-  for (int cr = 0; cr < DS2_MAXCIN * 3; ++cr) {
+  for (int L = 0; L < 5; ++L) {
+    // window cr = 5h + L -> (ci, filter row); both candidates are wave-uniform, the half picks one
+    int ro[2], rm[2], ihcs[2], cics[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) win[j][cr] = 0;
-    if (cr >= a.cin * 3) continue;  // uniform
-    const int ci = cr / 3, r = cr - 3 * (cr / 3);
-    const int ih = 2 * oy - a.pt + r;
-    const bool rv = ih >= 0 && ih < a.h;
-    const int ihc = ih < 0 ? 0 : (ih >= a.h ? a.h - 1 : ih);
-    uint32_t d[3] = {0, 0, 0};
-    const long gofs = (((long)b * a.cin + ci) * a.h + ihc) * a.w + lcol;
-    const int8_t* src = a.x + gofs;
-    if (gofs + 12 <= tensor_bytes) {
-      __builtin_memcpy(d, src, 12);
+    for (int hh = 0; hh < 2; ++hh) {
+      const int cr = 5 * hh + L;
+      const int ci = cr / 3, r3 = cr % 3;
+      const int ih = 2 * oy - a.pt + r3;
+      const bool rv = ih >= 0 && ih < a.h && cr < ncr;
+      ihcs[hh] = ih < 0 ? 0 : (ih >= a.h ? a.h - 1 : ih);
+      cics[hh] = ci < a.cin ? ci : a.cin - 1;
+      ro[hh] = img_base + (cics[hh] * a.h + ihcs[hh]) * a.w;
+      rm[hh] = rv ? -1 : 0;
+    }
+    const uint32_t rmask = (uint32_t)(h ? rm[1] : rm[0]);
+    uint32_t d[3];
+    if (GUARD) {
+      const uint32_t nomask[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+      const int cic = h ? cics[1] : cics[0], ihc = h ? ihcs[1] : ihcs[0];
+      dw_load_row<3, true>(a.x + img_base + (cic * a.h) * a.w, ihc, a.h, a.w, lcol, sh,
+                           tensor_bytes - img_base - (long)(cic * a.h) * a.w, nomask, d);
     } else {
-      for (int i = 0; i < 12; ++i)
-        if (gofs + i < tensor_bytes) d[i >> 2] |= (uint32_t)(uint8_t)src[i] << (8 * (i & 3));
-    }
-    if (sh) {
-      const int s8 = 8 * sh;
-      d[2] = (d[2] << s8) | (d[1] >> (32 - s8));
-      d[1] = (d[1] << s8) | (d[0] >> (32 - s8));
-      d[0] = d[0] << s8;
+      const uint32_t off = (uint32_t)((h ? ro[1] : ro[0]) + start);
+      __builtin_memcpy(d, a.x + off, 12);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) d[i] = rv ? (d[i] & cmask[i]) : 0u;
-    win[0][cr] = d[0];
-    win[1][cr] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
-    win[2][cr] = d[1];
-    win[3][cr] = __builtin_amdgcn_alignbyte(d[2], d[1], 2);
+    for (int i = 0; i < 3; ++i) d[i] &= cmask[i] & rmask;
+    win[0][L] = d[0];
+    win[1][L] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
+    win[2][L] = d[1];
+    win[3][L] = __builtin_amdgcn_alignbyte(d[2], d[1], 2);
   }
-  // B fragments: lane half h holds k = 16h .. 16h+15
   v4i bf[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t l0 = ds2_kdword<0>(win[j], K), l1 = ds2_kdword<4>(win[j], K), l2 = ds2_kdword<8>(win[j], K),
-                   l3 = ds2_kdword<12>(win[j], K);
-    const uint32_t u0 = ds2_kdword<16>(win[j], K), u1 = ds2_kdword<20>(win[j], K), u2 = ds2_kdword<24>(win[j], K),
-                   u3 = ds2_kdword<28>(win[j], K);
-    bf[j][0] = (int)(h ? u0 : l0);
-    bf[j][1] = (int)(h ? u1 : l1);
-    bf[j][2] = (int)(h ? u2 : l2);
-    bf[j][3] = (int)(h ? u3 : l3);
+    bf[j][0] = (int)__builtin_amdgcn_perm(win[j][1], win[j][0], 0x04020100u);
+    bf[j][1] = (int)__builtin_amdgcn_perm(win[j][2], win[j][1], 0x05040201u);
+    bf[j][2] = (int)__builtin_amdgcn_perm(win[j][3], win[j][2], 0x06050402u);
+    bf[j][3] = (int)(win[j][4] & 0x00ffffffu);
   }
 
   const int hw = oy * a.ow + 4 * xq;
@@ -350,26 +332,41 @@ __global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, con
     }
     if (qvalid) {
       if (OUT == OUT_I32) {
-        gemm_epilogue<1, OUT, VEC_STORE, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
+        gemm_epilogue<1, OUT, true, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
       } else {
         switch (a.act) {
-          case ACT_RELU: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
-          case ACT_RELU6: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
-          case ACT_LEAKY: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
-          default: gemm_epilogue<1, OUT, VEC_STORE, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+          case ACT_RELU: gemm_epilogue<1, OUT, true, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+          case ACT_RELU6: gemm_epilogue<1, OUT, true, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+          case ACT_LEAKY: gemm_epilogue<1, OUT, true, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+          default: gemm_epilogue<1, OUT, true, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
         }
       }
     }
   }
 }
 
-// A fragments: tile mt, lane (r = lane&31, h = lane>>5), byte j  <-  W[mt*32 + r][k = 16h + j], k = ci*9 + r3*3 + q
+template <int OUT, bool MFULL>
+__global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, const int8_t* __restrict__ afrag) {
+  __shared__ __attribute__((aligned(16))) float lsb_all[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* lsb = lsb_all[wave];
+  // only the first rows of the first image / the last rows of the last image can touch bytes outside the tensor
+  const bool guard = (blockIdx.z == 0 && blockIdx.y == 0) || (blockIdx.z + 1 == gridDim.z && blockIdx.y + 1 == gridDim.y);
+  if (guard) stem_mfma_body<OUT, MFULL, true>(a, afrag, lsb, lane, wave);
+  else stem_mfma_body<OUT, MFULL, false>(a, afrag, lsb, lane, wave);
+}
+
+// A fragments: tile mt, lane (r = lane&31, h = lane>>5), byte j  <-  W[mt*32 + r][window cr = 5h + j/3][tap j%3]
+// (h = 0: j < 15, h = 1: j < 12 and cr < 3*Cin; zero elsewhere) -- the k order of stem_mfma_body.
 __global__ void pack_conv3x3s2_mfma_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ afrag, int cin, int cout) {
   const int total = ((cout + 31) / 32) * 1024;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int j = idx & 15, lane = (idx >> 4) & 63, mt = idx >> 10;
-    const int co = mt * 32 + (lane & 31), k = 16 * (lane >> 5) + j;
-    afrag[idx] = (co < cout && k < cin * 9) ? w[(size_t)co * cin * 9 + k] : (int8_t)0;
+    const int co = mt * 32 + (lane & 31), hh = lane >> 5;
+    const int cr = 5 * hh + j / 3, q = j % 3;
+    const bool used = j < 15 && cr < cin * 3 && co < cout;
+    afrag[idx] = used ? w[((size_t)co * cin * 3 + cr) * 3 + q] : (int8_t)0;
   }
 }
 
@@ -389,17 +386,25 @@ void launch_conv3x3s2_direct(const DirectS2Args& a, int out, hipStream_t s) {
     mfma_env = e ? atoi(e) : 1;
   }
   const size_t esz = out == OUT_I8 ? 1 : 4;
-  if (mfma_env && a.cin * 9 <= 32 && (a.ow & 3) == 0 && ((uintptr_t)a.y & (4 * esz - 1)) == 0) {
-    const long quads = (long)a.n * a.oh * (a.ow >> 2);
-    const unsigned blocks = (unsigned)((quads + 127) / 128);
+  const long tensor = (long)a.n * a.cin * a.h * a.w;
+  const int owq = a.ow >> 2;
+  if (mfma_env && a.cin * 3 <= 9 && (a.ow & 3) == 0 && ((uintptr_t)a.y & (4 * esz - 1)) == 0 && tensor < (1L << 31) &&
+      8 * (owq - 1) - a.pl < a.w && a.n <= 65535 && (a.oh + 3) / 4 <= 65535) {
+    const dim3 blocks((unsigned)((owq + 31) / 32), (unsigned)((a.oh + 3) / 4), (unsigned)a.n);
     const int8_t* afrag = reinterpret_cast<const int8_t*>(a.wp) + ds2_dot4_bytes(a.cin, a.cout);
-    if (out == OUT_I32) hipLaunchKernelGGL((conv3x3s2_mfma_kernel<OUT_I32, true>), dim3(blocks), dim3(256), 0, s, a, afrag);
-    else if (out == OUT_F32) hipLaunchKernelGGL((conv3x3s2_mfma_kernel<OUT_F32, true>), dim3(blocks), dim3(256), 0, s, a, afrag);
-    else hipLaunchKernelGGL((conv3x3s2_mfma_kernel<OUT_I8, true>), dim3(blocks), dim3(256), 0, s, a, afrag);
+    const bool mfull = a.cout % 32 == 0;
+#define PLHIP_STEM(O)                                                                                       \
+  do {                                                                                                      \
+    if (mfull) hipLaunchKernelGGL((conv3x3s2_mfma_kernel<O, true>), blocks, dim3(256), 0, s, a, afrag);  \
+    else hipLaunchKernelGGL((conv3x3s2_mfma_kernel<O, false>), blocks, dim3(256), 0, s, a, afrag);       \
+  } while (0)
+    if (out == OUT_I32) PLHIP_STEM(OUT_I32);
+    else if (out == OUT_F32) PLHIP_STEM(OUT_F32);
+    else PLHIP_STEM(OUT_I8);
+#undef PLHIP_STEM
     return;
   }
-  const long owq = (a.ow + 3) >> 2;
-  const long total = (long)a.n * a.oh * owq;
+  const long total = (long)a.n * a.oh * ((a.ow + 3) >> 2);
   const unsigned blocks = (unsigned)((total + 255) / 256);
   const size_t lds = ((size_t)a.cin * 3 * a.coutp + DS2_COB + 2 * a.coutp) * 4;
   if (out == OUT_I32) hipLaunchKernelGGL((conv3x3s2_direct_kernel<OUT_I32>), dim3(blocks), dim3(256), lds, s, a);

@@ -258,6 +258,10 @@ __device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int r
 // instruction there carries 16 row segments of <= 14 bytes, 4.4 B per request.  With 64 % owq == 0 and RS | OH the 64 lanes
 // of a wave own one CONTIGUOUS output region ((64/owq) strips x RS rows x OW bytes); the results are assembled in LDS
 // and leave as contiguous dwords (256 B per store instruction).
+template <int OUT, int S, int RS, bool STAGE>
+__device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&in)[(RS - 1) * S + 3][S == 1 ? 2 : 3], long plane,
+                                             int ch, int oy0, int xq, bool live, long gid_in, uint8_t* wlds);
+
 template <int OUT, int S, int RS, bool TAIL, bool STAGE>
 __device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, uint8_t* wlds) {
   const bool live = gid_in < a.total_lanes;
@@ -310,6 +314,16 @@ __device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, 
 #pragma unroll
   for (int t = 0; t < NIN; ++t) dw_load_row<ND, TAIL>(xplane, iy0 + t, a.h, a.w, lcol, sh, plane_room, cmask, in[t]);
 
+  dw3x3_finish<OUT, S, RS, STAGE>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
+}
+
+// Second half of a strip, shared by the general and the fast row fetch: filter / scale fetch, the dot4 accumulation
+// over the NIN input rows in registers, requantisation and the store (direct, or staged through LDS).
+template <int OUT, int S, int RS, bool STAGE>
+__device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&in)[(RS - 1) * S + 3][S == 1 ? 2 : 3], long plane,
+                                             int ch, int oy0, int xq, bool live, long gid_in, uint8_t* wlds) {
+  constexpr int NIN = (RS - 1) * S + 3;
+  constexpr int ND = S == 1 ? 2 : 3;
   // filter rows packed (w0, w1, w2, 0): three unaligned dword loads; the last one is taken one byte early and shifted so
   // that it never reads past the end of the filter tensor
   uint32_t wr[3];
@@ -421,7 +435,73 @@ __device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, 
 #undef DW_ROWS
 }
 
+// Fast row fetch (the MobileNet geometry): vertical padding <= 1 and RS | OH, so only the first and the last input row
+// of a strip can fall outside the image, and the window is read from its true start column (pad bytes included: they
+// belong to the neighbouring row / plane and are masked to zero), so no per-row clamp, shift or validity select is
+// left: one 32-bit offset add, one load and ND ANDs per row.  (PMC: the general fetch spent ~14 VALU per row and the
+// large layers ran at 94 % VALU issue -- this op is VALU-bound before it is HBM-bound.)  The first workgroup (a window
+// may start before the tensor) and the last ones (it may end after it) use the guarded general body instead.
 template <int OUT, int S, int RS, bool STAGE>
+__device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, uint8_t* wlds) {
+  const bool live = gid_in < a.total_lanes;
+  const long gid = live ? gid_in : a.total_lanes - 1;
+  constexpr int NIN = (RS - 1) * S + 3;
+  constexpr int ND = S == 1 ? 2 : 3;
+  const int owq = (a.ow + 3) >> 2;
+  const int spp = a.oh / RS;
+  int xq, sidx, ch;
+  long plane;
+  if (a.fast_div) {
+    xq = (int)(gid & (owq - 1));
+    const long strip = gid >> a.owq_log2;
+    sidx = (int)(strip & (spp - 1));
+    plane = strip >> a.spp_log2;
+    ch = (int)(plane & (a.C - 1));
+  } else {
+    xq = (int)(gid % owq);
+    const long strip = gid / owq;
+    sidx = (int)(strip % spp);
+    plane = strip / spp;
+    ch = (int)(plane % a.C);
+  }
+  const int oy0 = sidx * RS;
+  const int iy0 = oy0 * S - a.pt;
+  const int start = 4 * xq * S - a.pl;
+  uint32_t cmask[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = start + 4 * d + i;
+      if (col >= 0 && col < a.w) m |= 0xffu << (8 * i);
+    }
+    cmask[d] = m;
+  }
+  // rows 1 .. NIN-2 are always inside the image
+  const uint32_t off1 = (uint32_t)((int)plane * a.h * a.w + (iy0 + 1) * a.w + start);
+  const bool top_ok = iy0 >= 0, bot_ok = iy0 + NIN - 1 < a.h;
+  uint32_t in[NIN][ND];
+#pragma unroll
+  for (int t = 0; t < NIN; ++t) {
+    uint32_t off = off1 + (uint32_t)((t - 1) * a.w);
+    if (t == 0) off = top_ok ? off : off1;
+    if (t == NIN - 1) off = bot_ok ? off : off1;
+    __builtin_memcpy(in[t], a.x + off, 4 * ND);
+  }
+#pragma unroll
+  for (int t = 0; t < NIN; ++t)
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      uint32_t m = cmask[d];
+      if (t == 0) m = top_ok ? m : 0u;
+      if (t == NIN - 1) m = bot_ok ? m : 0u;
+      in[t][d] &= m;
+    }
+  dw3x3_finish<OUT, S, RS, STAGE>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
+}
+
+template <int OUT, int S, int RS, bool STAGE, bool FASTV>
 __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dw_stage[];  // STAGE: 4 waves x stage_bytes
   long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -432,6 +512,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
   uint8_t* wlds = STAGE ? dw_stage + (threadIdx.x >> 6) * a.stage_bytes : nullptr;
   // only the last workgroups can touch the final bytes of the tensor: they alone pay for the guarded loads
   if (blockIdx.x + 4 >= gridDim.x) dw3x3_direct_body<OUT, S, RS, true, STAGE>(a, gid, wlds);
+  else if (FASTV && blockIdx.x != 0) dw3x3_fast_body<OUT, S, RS, STAGE>(a, gid, wlds);
   else dw3x3_direct_body<OUT, S, RS, false, STAGE>(a, gid, wlds);
 }
 
@@ -456,15 +537,28 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
   const bool stage = stage_env && OUT == OUT_I8 && a.ow <= 64 && a.owq_log2 >= 0 && owq <= 64 && a.oh % rs == 0;
   a.stage_bytes = stage ? (int)(((64 / owq) * rs * a.ow + 15) & ~15) : 0;
   const size_t lds = stage ? (size_t)4 * a.stage_bytes : 0;
-  if (stage) {
-    if (rs == 8) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 8, true>), dim3(blocks), dim3(256), lds, s, a);
-    else if (rs == 7) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 7, true>), dim3(blocks), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 4, true>), dim3(blocks), dim3(256), lds, s, a);
-    return;
+  // fast row fetch: only the first / last row of a strip can leave the image, windows start inside the row
+  static int fast_env = -1;
+  if (fast_env < 0) {
+    const char* e = getenv("PLHIP_DW_FASTV");
+    fast_env = e ? atoi(e) : 1;
   }
-  if (rs == 8) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 8, false>), dim3(blocks), dim3(256), 0, s, a);
-  else if (rs == 7) hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 7, false>), dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, 4, false>), dim3(blocks), dim3(256), 0, s, a);
+  const bool fastv = fast_env && a.pt <= 1 && (a.oh - 1) * S + 2 - a.pt <= a.h && a.oh % rs == 0 &&
+                     (owq - 1) * 4 * S - a.pl < a.w;
+#define PLHIP_DW_LAUNCH(RSV, ST, FV) \
+  hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, RSV, ST, FV>), dim3(blocks), dim3(256), lds, s, a)
+#define PLHIP_DW_RS(ST, FV)              \
+  do {                                   \
+    if (rs == 8) PLHIP_DW_LAUNCH(8, ST, FV);      \
+    else if (rs == 7) PLHIP_DW_LAUNCH(7, ST, FV); \
+    else PLHIP_DW_LAUNCH(4, ST, FV);              \
+  } while (0)
+  if (stage && fastv) PLHIP_DW_RS(true, true);
+  else if (stage) PLHIP_DW_RS(true, false);
+  else if (fastv) PLHIP_DW_RS(false, true);
+  else PLHIP_DW_RS(false, false);
+#undef PLHIP_DW_RS
+#undef PLHIP_DW_LAUNCH
 }
 
 static bool launch_dw_direct(const DwArgs& a, int out, hipStream_t s) {
