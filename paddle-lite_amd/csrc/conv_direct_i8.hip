@@ -253,7 +253,7 @@ __device__ __forceinline__ void stem_mfma_body(const DirectS2Args& a, const int8
   g.act = a.act;
   g.alpha = a.alpha;
   const v4i af0 = *reinterpret_cast<const v4i*>(afrag + (size_t)lane * 16);
-  if (OUT != OUT_I32) stage_scale_bias<1>(g, 0, lane, lsb);
+  if (OUT != OUT_I32) stage_scale_bias<1, OUT>(g, 0, lane, lsb);
 
   uint32_t cmask[3];
 #pragma unroll
@@ -321,7 +321,7 @@ __device__ __forceinline__ void stem_mfma_body(const DirectS2Args& a, const int8
     v4i af = af0;
     if (mt > 0) {
       af = *reinterpret_cast<const v4i*>(afrag + ((size_t)mt * 64 + lane) * 16);
-      if (OUT != OUT_I32) stage_scale_bias<1>(g, mt, lane, lsb);
+      if (OUT != OUT_I32) stage_scale_bias<1, OUT>(g, mt, lane, lsb);
     }
     v16i acc[1][4];
 #pragma unroll

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void fused_dwpw_kernel(FusedArgs a) {
 #pragma unroll
       for (int aa = 0; aa < MA; ++aa) a_cur[aa] = a_nxt[aa];
     }
-    if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
+    if (OUT != OUT_I32) store_scale_bias<MA, OUT>(lsb, lane, my_s, my_b);
     if (!cvalid || (a.pw.dbg & 4)) continue;
     if (OUT == OUT_I32) {
       gemm_epilogue<MA, OUT, false, false, ACT_NONE>(g, acc, mt, h, b, hw, lsb, room);

@@ -36,7 +36,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
                                               const float* lsb, int hwy_room) {
   // hwy_room: columns hw+i with i < hwy_room are real outputs (GEMM: HWY - hw, the im2col pitch pad; fused dw+pw: the
   // columns left in the output row)
-  const size_t ybase = (size_t)b * g.y_bstride + hw;
+  // address = per-lane part (image, column, the half's 4-row shift) + wave-uniform row offset: one 64-bit add per row
+  // instead of a per-lane integer multiply (quarter rate) per row
+  const size_t ylane = (size_t)b * g.y_bstride + hw + (size_t)(4 * h) * (uint32_t)g.HWY;
   const float hi2 = ACT == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
   const float lo2 = (ACT == ACT_RELU || ACT == ACT_RELU6) ? 0.f : -254.f;
 #pragma unroll
@@ -46,6 +48,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
     for (int gq = 0; gq < 4; ++gq) {
       const int m0 = mbase + 8 * gq + 4 * h;
       if (!MFULL && m0 >= g.M) continue;
+      const int mu0 = mbase + 8 * gq;  // uniform part of the row index
       // scale / bias come from LDS (staged at kernel start): a global load here would sit behind the previous rows'
       // stores in the in-order vmcnt queue and serialise the epilogue into one memory round trip per row group
       v4f sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
@@ -59,7 +62,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
         const int m = m0 + e;
         if (!MFULL && m >= g.M) continue;
         const int v0 = acc[a][0][r], v1 = acc[a][1][r], v2 = acc[a][2][r], v3 = acc[a][3][r];
-        const size_t yoff = ybase + (uint32_t)(m * g.HWY);  // one image's output is < 2^31 elements (checked on the host)
+        const size_t yoff = ylane + (size_t)((uint32_t)(mu0 + e) * (uint32_t)g.HWY);  // one image's output is < 2^31 elements (checked on the host)
         if (OUT == OUT_I32) {
           int* yp = reinterpret_cast<int*>(g.y) + yoff;
           if (VEC_STORE) {
@@ -96,7 +99,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
             if (2 < hwy_room) yp[2] = f[2];
           }
         } else {
-          const float s2 = sc[e] + sc[e], b2 = bi[e] + bi[e];
+          const float s2 = sc[e], b2 = bi[e];  // staged already doubled for int8 output (store_scale_bias)
           const int vv[4] = {v0, v1, v2, v3};
           uint32_t packed;
           if (ACT == ACT_RELU || ACT == ACT_RELU6) {
@@ -146,18 +149,22 @@ __device__ __forceinline__ void load_scale_bias(const GemmArgs& g, int mt, int l
     if (g.bias && m < g.M) b = g.bias[m];
   }
 }
-template <int MA>
+template <int MA, int OUT>
 __device__ __forceinline__ void store_scale_bias(float* lsb, int lane, float s, float b) {
+  if (OUT == OUT_I8) {  // the int8 requantisation works on doubled values (exact: power-of-two scaling)
+    s += s;
+    b += b;
+  }
   if (lane < MA * 32) {
     lsb[lane] = s;
     lsb[MA * 32 + lane] = b;
   }
 }
-template <int MA>
+template <int MA, int OUT>
 __device__ __forceinline__ void stage_scale_bias(const GemmArgs& g, int mt, int lane, float* lsb) {
   float s, b;
   load_scale_bias<MA>(g, mt, lane, s, b);
-  store_scale_bias<MA>(lsb, lane, s, b);
+  store_scale_bias<MA, OUT>(lsb, lane, s, b);
 }
 
 }  // namespace plhip

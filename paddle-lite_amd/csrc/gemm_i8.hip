@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
         acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[a], bf[i], acc[a][i], 0, 0, 0);
   }
 
-  if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
+  if (OUT != OUT_I32) store_scale_bias<MA, OUT>(lsb, lane, my_s, my_b);
   if (!nvalid || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
     gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
+  if (OUT != OUT_I32) store_scale_bias<MA, OUT>(lsb, lane, my_s, my_b);
   if (!nvalid || !mactive || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
     gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
     step(ks, integral_constant<int, 0>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
   }
 
-  if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
+  if (OUT != OUT_I32) store_scale_bias<MA, OUT>(lsb, lane, my_s, my_b);
   PLHIP_STAMP(STAMP_SLOTS - 4);
   if (nvalid && mactive && !(g.dbg & 1)) {
     if (OUT == OUT_I32) {
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(384, 2) void gemm_i8_ws_kernel(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if (OUT != OUT_I32) store_scale_bias<MA>(lsb, lane, my_s, my_b);
+  if (OUT != OUT_I32) store_scale_bias<MA, OUT>(lsb, lane, my_s, my_b);
   if (!nvalid || !mactive || (g.dbg & 1)) return;
   if (OUT == OUT_I32) {
     gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
