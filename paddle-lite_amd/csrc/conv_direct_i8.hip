@@ -256,16 +256,7 @@ __device__ __forceinline__ void stem_mfma_body(const DirectS2Args& a, const int8
   if (OUT != OUT_I32) stage_scale_bias<1, OUT>(g, 0, lane, lsb);
 
   uint32_t cmask[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = start + 4 * d + i;
-      if (col >= 0 && col < a.w) m |= 0xffu << (8 * i);
-    }
-    cmask[d] = m;
-  }
+  dw_col_masks<3>(start, a.w, cmask);  // -4 < start < w (host check)
   const int sh = start < 0 ? -start : 0;  // GUARD only
   int lcol = start + sh;
   if (lcol > a.w - 1) lcol = a.w - 1;

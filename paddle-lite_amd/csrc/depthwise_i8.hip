@@ -341,10 +341,6 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
   const float bi = a.bias ? a.bias[ch] : 0.f;
 
   int acc[RS][4];
-#pragma unroll
-  for (int o = 0; o < RS; ++o)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[o][j] = 0;
 
 #pragma unroll
   for (int t = 0; t < NIN; ++t) {
@@ -366,7 +362,8 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
       const int o = (t - r) / S;
       if (t - r < 0 || o >= RS) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[o][j] = __builtin_amdgcn_sdot4((int)win[j], (int)wr[r], acc[o][j], false);
+      for (int j = 0; j < 4; ++j)
+        acc[o][j] = r == 0 ? sdot4_first(win[j], wr[0]) : __builtin_amdgcn_sdot4((int)win[j], (int)wr[r], acc[o][j], false);
     }
   }
 
@@ -391,12 +388,23 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
     const int strip_l = lane >> a.owq_log2;              // strip index inside the wave
     const int lofs = strip_l * (RS * a.ow) + 4 * xq;     // byte offset of (row 0, quad) inside the wave's region
     if (live) {
+      if ((a.ow & 1) == 0) {
+        // even OW: every (row, quad) starts 2-byte aligned -> halfword writes (room is even: 2 or >= 4); uniform branch
+        uint8_t* dst = wlds + lofs;
 #pragma unroll
-      for (int o = 0; o < RS; ++o) {
-        uint8_t* dst = wlds + lofs + o * a.ow;
+        for (int o = 0; o < RS; ++o) {
+          *reinterpret_cast<uint16_t*>(dst) = (uint16_t)pk[o];
+          if (room >= 4) *reinterpret_cast<uint16_t*>(dst + 2) = (uint16_t)(pk[o] >> 16);
+          dst += a.ow;
+        }
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < room) dst[j] = (uint8_t)(pk[o] >> (8 * j));
+        for (int o = 0; o < RS; ++o) {
+          uint8_t* dst = wlds + lofs + o * a.ow;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < room) dst[j] = (uint8_t)(pk[o] >> (8 * j));
+        }
       }
     }
     // the wave's region in global memory starts at the output offset of its lane 0
@@ -407,6 +415,12 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
     const int nstrips = (int)((lanes_left < 64 ? lanes_left : 64) >> a.owq_log2);
     const int region = nstrips * RS * a.ow;  // bytes
     int8_t* yb = reinterpret_cast<int8_t*>(a.y) + wbase;
+    if ((((uintptr_t)yb | (uintptr_t)region) & 15) == 0) {
+      // the common case (full waves, 16-byte multiple regions): 16 bytes per lane and instruction
+      for (int i = lane * 16; i < region; i += 64 * 16)
+        *reinterpret_cast<v4i*>(yb + i) = *reinterpret_cast<const v4i*>(wlds + i);
+      return;
+    }
     const int head = (int)((4 - ((uintptr_t)yb & 3)) & 3);  // bytes before the first aligned dword
     for (int i = lane; i < head && i < region; i += 64) yb[i] = (int8_t)wlds[i];
     const int ndw = region > head ? (region - head) >> 2 : 0;
@@ -468,16 +482,7 @@ __device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, ui
   const int iy0 = oy0 * S - a.pt;
   const int start = 4 * xq * S - a.pl;
   uint32_t cmask[ND];
-#pragma unroll
-  for (int d = 0; d < ND; ++d) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = start + 4 * d + i;
-      if (col >= 0 && col < a.w) m |= 0xffu << (8 * i);
-    }
-    cmask[d] = m;
-  }
+  dw_col_masks<ND>(start, a.w, cmask);
   // rows 1 .. NIN-2 are always inside the image
   const uint32_t off1 = (uint32_t)((int)plane * a.h * a.w + (iy0 + 1) * a.w + start);
   const bool top_ok = iy0 >= 0, bot_ok = iy0 + NIN - 1 < a.h;

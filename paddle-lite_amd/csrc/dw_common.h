@@ -25,6 +25,31 @@ __device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, flo
   return pack4_i8(q[0], q[1], q[2], q[3]);
 }
 
+// Byte-validity masks of a row window of ND dwords whose byte 0 is input column `start` (may be negative: left padding):
+// byte i is kept iff 0 <= start + i < w.  Built with two 64-bit shifts instead of a compare / select per byte (the
+// depthwise kernels are VALU-bound; the per-byte form cost ~30 VALU per dword).  Needs -4 < start and start < w.
+template <int ND>
+__device__ __forceinline__ void dw_col_masks(int start, int w, uint32_t (&cmask)[ND]) {
+  const int lo = start < 0 ? -start : 0;                     // invalid bytes at the low end (<= 3)
+  const int hi = w - start < 4 * ND ? w - start : 4 * ND;    // first invalid byte at the high end (>= 1, > lo)
+  const int hi8 = hi < 8 ? hi : 8;
+  const unsigned long long m01 = (~0ull >> (64 - 8 * (hi8 - lo))) << (8 * lo);
+  cmask[0] = (uint32_t)m01;
+  if (ND > 1) cmask[1] = (uint32_t)(m01 >> 32);
+  if (ND > 2) {
+    const int n2 = hi - 8 < 0 ? 0 : hi - 8;                  // valid bytes of dword 2 (0..4)
+    cmask[2] = (uint32_t)((1ull << (8 * n2)) - 1ull);
+  }
+}
+
+// first tap of an accumulator: VOP3P form with the constant 0 as addend (the builtin selects v_dot4c, which needs the
+// accumulator zeroed by a separate v_mov first)
+__device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b) {
+  int r;
+  asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // Row fetch, branch free: the row index is clamped (an out-of-image row only zeroes the masks), the column start is
 // clamped for the left border (the missing bytes are shifted in as zeros), and — only in the TAIL instantiation, which
 // the last workgroup alone runs — the address is pulled back so that the load never crosses the end of the tensor.
