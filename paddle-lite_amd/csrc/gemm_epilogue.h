@@ -33,9 +33,10 @@ __device__ __forceinline__ float act2(float y2, float alpha) {  // activation on
 
 template <int MA, int OUT, bool VEC_STORE, bool MFULL, int ACT>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&acc)[MA][4], int mt, int h, int b, int hw,
-                                              const float* lsb, int hwy_room) {
+                                              const float* lsb, int hwy_room, int skip = 0) {
   // hwy_room: columns hw+i with i < hwy_room are real outputs (GEMM: HWY - hw, the im2col pitch pad; fused dw+pw: the
-  // columns left in the output row)
+  // columns left in the output row); skip: the lane's first `skip` columns are duplicates and are not stored (the
+  // end-aligned last 16-byte piece of an image in the LDS-DMA kernel when HW % 4 != 0)
   // address = per-lane part (image, column, the half's 4-row shift) + wave-uniform row offset: one 64-bit add per row
   // instead of a per-lane integer multiply (quarter rate) per row
   const size_t ylane = (size_t)b * g.y_bstride + hw + (size_t)(4 * h) * (uint32_t)g.HWY;
@@ -68,13 +69,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
           if (VEC_STORE) {
             v4i v = {v0, v1, v2, v3};
             *reinterpret_cast<v4i*>(yp) = v;
-          } else if (hwy_room >= 4) {
+          } else if (hwy_room >= 4 && skip == 0) {
             v4i v = {v0, v1, v2, v3};
             __builtin_memcpy(yp, &v, 16);  // possibly unaligned: fine for global memory
           } else {
-            if (0 < hwy_room) yp[0] = v0;
-            if (1 < hwy_room) yp[1] = v1;
-            if (2 < hwy_room) yp[2] = v2;
+            if (0 >= skip && 0 < hwy_room) yp[0] = v0;
+            if (1 >= skip && 1 < hwy_room) yp[1] = v1;
+            if (2 >= skip && 2 < hwy_room) yp[2] = v2;
+            if (3 >= skip && 3 < hwy_room) yp[3] = v3;
           }
         } else if (OUT == OUT_F32) {
           const float s = sc[e], bb = bi[e];
@@ -90,13 +92,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
           if (VEC_STORE) {
             v4f v = {f[0], f[1], f[2], f[3]};
             *reinterpret_cast<v4f*>(yp) = v;
-          } else if (hwy_room >= 4) {
+          } else if (hwy_room >= 4 && skip == 0) {
             v4f v = {f[0], f[1], f[2], f[3]};
             __builtin_memcpy(yp, &v, 16);
           } else {
-            if (0 < hwy_room) yp[0] = f[0];
-            if (1 < hwy_room) yp[1] = f[1];
-            if (2 < hwy_room) yp[2] = f[2];
+            if (0 >= skip && 0 < hwy_room) yp[0] = f[0];
+            if (1 >= skip && 1 < hwy_room) yp[1] = f[1];
+            if (2 >= skip && 2 < hwy_room) yp[2] = f[2];
+            if (3 >= skip && 3 < hwy_room) yp[3] = f[3];
           }
         } else {
           const float s2 = sc[e], b2 = bi[e];  // staged already doubled for int8 output (store_scale_bias)
@@ -122,13 +125,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
           int8_t* yp = reinterpret_cast<int8_t*>(g.y) + yoff;
           if (VEC_STORE) {
             *reinterpret_cast<uint32_t*>(yp) = packed;
-          } else if (hwy_room >= 4) {
+          } else if (hwy_room >= 4 && skip == 0) {
             __builtin_memcpy(yp, &packed, 4);  // possibly unaligned: fine for global memory
           } else {
-            if (0 < hwy_room) yp[0] = (int8_t)(packed & 0xff);
-            if (1 < hwy_room) yp[1] = (int8_t)((packed >> 8) & 0xff);
-            if (2 < hwy_room) yp[2] = (int8_t)((packed >> 16) & 0xff);
-            if (3 < hwy_room) yp[3] = (int8_t)(packed >> 24);
+            if (0 >= skip && 0 < hwy_room) yp[0] = (int8_t)(packed & 0xff);
+            if (1 >= skip && 1 < hwy_room) yp[1] = (int8_t)((packed >> 8) & 0xff);
+            if (2 >= skip && 2 < hwy_room) yp[2] = (int8_t)((packed >> 16) & 0xff);
+            if (3 >= skip && 3 < hwy_room) yp[3] = (int8_t)(packed >> 24);
           }
         }
       }

@@ -310,13 +310,17 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   // pieces (ONE 1-KiB LDS-DMA instruction per wave and K-step instead of four 256-byte ones: the loop was bound by the
   // number of vector-memory instructions, not by bytes).  The last piece of an image is END-aligned (source columns
   // HWX-16 .. HWX-1), so nothing is read outside the plane; its first 16-r columns duplicate earlier ones and are
-  // never stored (r = HWX % 16; HWX % 4 == 0 keeps each lane's 4 columns all-real or all-duplicate).
+  // never stored (r = HWX % 16; with HWX % 4 != 0 one lane per image holds both kinds: `skip`).  Neither the rows nor
+  // the pieces need any alignment: LDS-DMA takes byte-aligned global addresses (tools/probe_dma_unaligned.hip).
   const int HWP = (g.HWX + 15) & ~15, full16 = g.HWX & ~15, rem16 = g.HWX & 15;
   int n4 = nt * 128 + 4 * c;
   int b = n4 / HWP;
   int j = n4 - b * HWP;
-  const bool nvalid = b < g.NB && (j < full16 || j >= HWP - rem16);
-  if (!nvalid) { b = 0; j = 0; }
+  // lane's columns j .. j+3: real if below full16, or (last piece) from column HWP - rem16 on; `skip` leading duplicates
+  int skip = j < full16 ? 0 : HWP - rem16 - j;
+  skip = skip < 0 ? 0 : skip;
+  const bool nvalid = b < g.NB && skip < 4;
+  if (!nvalid) { b = 0; j = 0; skip = 0; }
   const int hw = j < full16 ? j : j + rem16 - 16;
   // my 16-byte piece of the B tile: row 8*wave + lane/8 of the K-step, columns 16*(lane&7) ...
   const int prow = 8 * wave + (lane >> 3);
@@ -468,13 +472,13 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   PLHIP_STAMP(STAMP_SLOTS - 4);
   if (nvalid && mactive && !(g.dbg & 1)) {
     if (OUT == OUT_I32) {
-      gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);
+      gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw, skip);
     } else {
       switch (g.act) {
-        case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
-        case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
-        case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
-        default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw); break;
+        case ACT_RELU: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU>(g, acc, mt, h, b, hw, lsb, g.HWY - hw, skip); break;
+        case ACT_RELU6: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_RELU6>(g, acc, mt, h, b, hw, lsb, g.HWY - hw, skip); break;
+        case ACT_LEAKY: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_LEAKY>(g, acc, mt, h, b, hw, lsb, g.HWY - hw, skip); break;
+        default: gemm_epilogue<MA, OUT, VEC_STORE, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw, skip); break;
       }
     }
   }
@@ -721,7 +725,7 @@ int debug_read_stamps(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
 }
 
-static int gemm_variant() {  // PLHIP_GEMM_VARIANT: 0 auto, 1 private-tile kernel, 2 register-staged LDS kernel, 3 LDS-DMA ring, 4 deep ring, 5 wave-specialised
+static int gemm_variant() {  // PLHIP_GEMM_VARIANT: 0 auto, 1 private-tile kernel, 2 register-staged LDS kernel, 3 LDS-DMA ring, 5 wave-specialised
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("PLHIP_GEMM_VARIANT");
@@ -746,28 +750,21 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
       hipLaunchKernelGGL((gemm_i8_ws_kernel<OUT, false, false>), dim3(blocks), dim3(384), 0, s, g);
     return;
   }
-  const bool use_dma = aligned && g.HWX >= 16 && g.KS >= (var == 4 ? 8 : 4) && (var == 3 || var == 4 || (var == 0 && g.MT >= 4));
+  const bool use_dma = g.HWX >= 16 && g.KS >= 4 && (var == 3 || (var == 0 && g.MT >= 4));
   if (use_dma) {
     g.NT = (int)(((long)g.NB * ((g.HWX + 15) & ~15) + 127) / 128);  // 16-byte padded column space of this kernel
     const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
-    const bool deep = var == 4;
-    const int depth = deep ? 8 : 4;
-    const size_t lds = (size_t)(depth + 1) * (4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4 + 4 * STAMP_SLOTS * 8;
-#define PLHIP_LAUNCH_DMA(VS, MF, DD)                                                                              \
+    const size_t lds = (size_t)(4 + 1) * (4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4 + 4 * STAMP_SLOTS * 8;
+#define PLHIP_LAUNCH_DMA(VS, MF)                                                                                  \
   do {                                                                                                            \
-    auto kfn = gemm_i8_dma_kernel<MA, OUT, VS, MF, DD>;                                                           \
+    auto kfn = gemm_i8_dma_kernel<MA, OUT, VS, MF, 4>;                                                            \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, s, g);                                                  \
   } while (0)
-    if (deep) {
-      if (vec_store && mfull) PLHIP_LAUNCH_DMA(true, true, 8);
-      else if (vec_store) PLHIP_LAUNCH_DMA(true, false, 8);
-      else PLHIP_LAUNCH_DMA(false, false, 8);
-    } else {
-      if (vec_store && mfull) PLHIP_LAUNCH_DMA(true, true, 4);
-      else if (vec_store) PLHIP_LAUNCH_DMA(true, false, 4);
-      else PLHIP_LAUNCH_DMA(false, false, 4);
-    }
+    if (vec_store && mfull) PLHIP_LAUNCH_DMA(true, true);
+    else if (vec_store) PLHIP_LAUNCH_DMA(true, false);
+    else if (mfull) PLHIP_LAUNCH_DMA(false, true);
+    else PLHIP_LAUNCH_DMA(false, false);
 #undef PLHIP_LAUNCH_DMA
     return;
   }
