@@ -127,7 +127,8 @@ plhip_status plhip_dwpw_fused_int8(plhip_ctx* ctx, const plhip_conv_desc* dw, co
  * Replaces: FcCompute<kInt8,*>::Run (lite/kernels/arm/fc_compute.cc:229-344) -> gemm_s8 / gemv_int8
  * (lite/backends/arm/math/gemm_s8.cc:23-47, gemv_arm_int8.cc:701-760).
  * x [m,k] int8 row-major; w [k,n] int8 (Paddle "mul" layout); scale/bias per output column n.
- * Pre-pack ([k/4][n][4], zero padded) replaces the weight transpose of fc_compute.cc:53-62. */
+ * Pre-pack (an opaque block of plhip_fc_packed_weight_bytes: a [k/4][n][4] copy for the dot4 kernels followed by the
+ * MFMA A-fragment order, both zero padded) replaces the weight transpose of fc_compute.cc:53-62. */
 size_t plhip_fc_packed_weight_bytes(int k, int n);
 plhip_status plhip_pack_fc_weights(plhip_ctx* ctx, int k, int n, const int8_t* w_kn, void* w_packed);
 plhip_status plhip_fc_int8(plhip_ctx* ctx, int m, int k, int n, const int8_t* x, const void* w_packed,

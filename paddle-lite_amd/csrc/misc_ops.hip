@@ -8,6 +8,8 @@
 // All four are tiny in the MobileNet graph (FC = 1 MMAC / image); they are kept on device so that the
 // whole graph runs without host round trips.  FC uses v_dot4_i32_i8 on a [k/4][n][4] pre-packed weight:
 // lanes walk n (coalesced dword per k-quad), the x dwords are wave-uniform.
+#include <stdlib.h>
+
 #include "plhip_device.h"
 #include "plhip_kernels.h"
 
@@ -146,6 +148,99 @@ __global__ __launch_bounds__(256) void fc_i8_fast_kernel(const int8_t* __restric
   }
 }
 
+// ---- MFMA path (k % 32 == 0): Y^T tile = W^T (32 output features x K) * X^T (K x 32 batch rows).  Both operands are
+// K-contiguous per lane as v_mfma_i32_32x32x32_i8 wants them: A = the pre-packed weights (second half of the packed
+// block, fragment order), B = 16 consecutive bytes of an x row -- no transposes anywhere.  A lane ends with 4
+// consecutive output features of one batch row: one 16-byte fp32 store.  The 4 waves of a block split K (all their
+// loads are issued before the first MFMA: the op is one memory round trip long) and meet in LDS.  The dot4 kernel
+// above walked K with one dependent global load per 16 k: 16 serial round trips, 15 us for 131 MMAC.
+size_t fc_dot4_bytes(int k, int n) { return (((size_t)((k + 3) / 4) * n * 4) + 15) & ~(size_t)15; }
+size_t fc_packed_bytes(int k, int n) { return fc_dot4_bytes(k, n) + (size_t)((n + 31) / 32) * ((k + 31) / 32) * 1024; }
+
+__global__ void pack_fc_mfma_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp, int k, int n) {
+  const int KS = (k + 31) / 32;
+  const size_t total = (size_t)((n + 31) / 32) * KS * 1024;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = idx & 15, lane = (idx >> 4) & 63;
+    const size_t t = idx >> 10;
+    const int ks = (int)(t % KS), nt = (int)(t / KS);
+    const int nn = nt * 32 + (lane & 31), kk = ks * 32 + 16 * (lane >> 5) + j;
+    wp[idx] = (nn < n && kk < k) ? w[(size_t)kk * n + nn] : (int8_t)0;
+  }
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void fc_i8_mfma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ wfrag,
+                                                         const float* __restrict__ scale, const float* __restrict__ bias,
+                                                         void* __restrict__ y, int m, int k, int n, int relu) {
+  __shared__ int red[4][16][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int c = lane & 31, h = lane >> 5;
+  const int nt = blockIdx.x, mt = blockIdx.y;
+  const int KS = k >> 5;
+  const int ks0 = (KS * wave) >> 2, ks1 = (KS * (wave + 1)) >> 2;
+  const int mrow = mt * 32 + c < m ? mt * 32 + c : m - 1;
+  const int8_t* xb = x + (size_t)mrow * k + 16 * h;
+  const int8_t* ab = wfrag + (size_t)nt * KS * 1024 + lane * 16;
+  // scale / bias of the 4 features this lane finishes (register group = wave): issued first, consumed last
+  const int n0 = nt * 32 + 8 * wave + 4 * h;
+  float sc4[4] = {1.f, 1.f, 1.f, 1.f}, bi4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (OUT != OUT_I32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sc4[e] = scale[n0 + e < n ? n0 + e : n - 1];
+    if (bias) {  // uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bi4[e] = bias[n0 + e < n ? n0 + e : n - 1];
+    }
+  }
+  v16i acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0;
+  for (int ks = ks0; ks < ks1; ks += 8) {
+    v4i af[8], bf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = ks + u < ks1 ? ks + u : ks1 - 1;  // surplus slots repeat the last step and are not multiplied
+      af[u] = *reinterpret_cast<const v4i*>(ab + (size_t)kk * 1024);
+      __builtin_memcpy(&bf[u], xb + (size_t)kk * 32, 16);  // x rows need no alignment
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (ks + u < ks1) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[u], bf[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  // wave w finishes register group w: rows (features) nt*32 + 8w + 4h + (0..3), column (batch row) mt*32 + c
+  const int mcol = mt * 32 + c;
+  if (mcol >= m || n0 >= n) return;
+  float f[4];
+  int a4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = 4 * wave + e;
+    a4[e] = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+    f[e] = epilogue_f32(a4[e], sc4[e], bi4[e], relu ? ACT_RELU : ACT_NONE, 0.f);  // fp32-out spec
+  }
+  const size_t off = (size_t)mcol * n + n0;
+  const int cnt = n - n0 < 4 ? n - n0 : 4;
+  if (OUT == OUT_I32) {
+    int* yp = reinterpret_cast<int*>(y) + off;
+    if (cnt == 4) __builtin_memcpy(yp, a4, 16);
+    else for (int e = 0; e < cnt; ++e) yp[e] = a4[e];
+  } else if (OUT == OUT_F32) {
+    float* yp = reinterpret_cast<float*>(y) + off;
+    if (cnt == 4) __builtin_memcpy(yp, f, 16);
+    else for (int e = 0; e < cnt; ++e) yp[e] = f[e];
+  } else {
+    int8_t* yp = reinterpret_cast<int8_t*>(y) + off;
+    const uint32_t pk = pack4_i8(round_sat_i8(f[0]), round_sat_i8(f[1]), round_sat_i8(f[2]), round_sat_i8(f[3]));
+    if (cnt == 4) __builtin_memcpy(yp, &pk, 4);
+    else for (int e = 0; e < cnt; ++e) yp[e] = (int8_t)(pk >> (8 * e));
+  }
+}
+
 // q = clamp(round_half_away(x * (1.f/scale)), -127, 127)   type_trans.cc:45,183-184
 __global__ void calib_f32_to_i8_kernel(const float* __restrict__ x, int8_t* __restrict__ y, float inv_scale, int64_t count, int vec) {
   const int64_t nq = vec ? count >> 2 : 0;
@@ -219,10 +314,27 @@ void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s)
   size_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_fc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w_kn, wp, k, n);
+  const size_t ftotal = (size_t)((n + 31) / 32) * ((k + 31) / 32) * 1024;
+  size_t fblocks = (ftotal + 255) / 256;
+  if (fblocks > 4096) fblocks = 4096;
+  hipLaunchKernelGGL(pack_fc_mfma_kernel, dim3((unsigned)fblocks), dim3(256), 0, s, w_kn, wp + fc_dot4_bytes(k, n), k, n);
 }
 
 void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const float* bias, void* y, int m, int k, int n,
                int relu, int out, hipStream_t s) {
+  static int fc_mfma_env = -1;
+  if (fc_mfma_env < 0) {
+    const char* e = getenv("PLHIP_FC_MFMA");
+    fc_mfma_env = e ? atoi(e) : 1;
+  }
+  if (fc_mfma_env && (k & 31) == 0) {
+    dim3 grid((n + 31) / 32, (m + 31) / 32);
+    const int8_t* wfrag = wp + fc_dot4_bytes(k, n);
+    if (out == OUT_I32) hipLaunchKernelGGL((fc_i8_mfma_kernel<OUT_I32>), grid, dim3(256), 0, s, x, wfrag, scale, bias, y, m, k, n, relu);
+    else if (out == OUT_F32) hipLaunchKernelGGL((fc_i8_mfma_kernel<OUT_F32>), grid, dim3(256), 0, s, x, wfrag, scale, bias, y, m, k, n, relu);
+    else hipLaunchKernelGGL((fc_i8_mfma_kernel<OUT_I8>), grid, dim3(256), 0, s, x, wfrag, scale, bias, y, m, k, n, relu);
+    return;
+  }
   const size_t lds = (size_t)FCF_MB * k > (size_t)4 * FCF_MB * 64 * 4 ? (size_t)FCF_MB * k : (size_t)4 * FCF_MB * 64 * 4;
   if ((k & 15) == 0 && ((uintptr_t)x & 15) == 0 && lds <= 64 * 1024) {
     dim3 grid((n + 63) / 64, (m + FCF_MB - 1) / FCF_MB);

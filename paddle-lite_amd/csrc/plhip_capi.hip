@@ -459,7 +459,7 @@ plhip_status plhip_dwpw_fused_int8(plhip_ctx* ctx, const plhip_conv_desc* dw, co
 // ------------------------------------------------------------------ fc
 size_t plhip_fc_packed_weight_bytes(int k, int n) {
   if (k < 1 || n < 1) return 0;
-  return (size_t)((k + 3) / 4) * n * 4;
+  return plhip::fc_packed_bytes(k, n);  // [dot4 layout][MFMA A fragments]
 }
 
 plhip_status plhip_pack_fc_weights(plhip_ctx* ctx, int k, int n, const int8_t* w_kn, void* w_packed) {

@@ -87,6 +87,7 @@ size_t conv3x3s2_direct_packed_bytes(int cin, int cout);
 void launch_pack_conv3x3s2_direct(const int8_t* w_oihw, uint32_t* wp, int cin, int cout, hipStream_t s);
 void launch_conv3x3s2_direct(const DirectS2Args& a, int out, hipStream_t s);
 
+size_t fc_packed_bytes(int k, int n);
 void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s);
 void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const float* bias, void* y, int m, int k, int n,
                int relu, int out, hipStream_t s);

@@ -214,7 +214,8 @@ def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
     assert np.array_equal(gpu_ctx.fc(g["x"], g["w"], g["scale8"], g["bias8"], 1, capi.OUT_I8), g["y_i8"])
     rng = np.random.default_rng(108)
     # fc_compute.cc shapes: MobileNet tail (k=1024, n=1000) at a ragged batch; k % 4 != 0 tail
-    for (m, k, n) in [(5, 1024, 1000), (1, 7, 3), (17, 66, 257)]:
+    # (k % 32 == 0 -> MFMA kernel, incl. ragged m / n tiles and a split-K remainder; otherwise the dot4 kernels)
+    for (m, k, n) in [(5, 1024, 1000), (1, 7, 3), (17, 66, 257), (70, 64, 37), (33, 96, 1000), (128, 1024, 1000)]:
         x = rng.integers(-127, 128, (m, k)).astype(np.int8)
         w = rng.integers(-127, 128, (k, n)).astype(np.int8)
         sc = ((1 + np.arange(n) % 5) / 127.0 / 127.0).astype(np.float32)
@@ -222,6 +223,9 @@ def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
         y_ref, acc_ref = plref.fc(x, w, bi, sc, False, False)
         assert np.array_equal(gpu_ctx.fc(x, w, None, None, 0, capi.OUT_I32), acc_ref)
         np.testing.assert_allclose(gpu_ctx.fc(x, w, sc, bi, 0, capi.OUT_F32), y_ref, rtol=FP32_RTOL, atol=1e-7)
+        sc8 = (sc * 40.0).astype(np.float32)  # int8-out: scale folded with 1 / out_scale
+        y8_ref, _ = plref.fc(x, w, bi, sc8, True, True)
+        assert np.array_equal(gpu_ctx.fc(x, w, sc8, bi, 1, capi.OUT_I8), y8_ref)
     c = load_golden(golden_files("calib")[0])
     assert np.array_equal(gpu_ctx.calib_f32_to_i8(c["x"], float(c["scale"])), c["q"])
     assert np.array_equal(gpu_ctx.calib_i8_to_f32(c["q"], float(c["scale"])), c["deq"])
