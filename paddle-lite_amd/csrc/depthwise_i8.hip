@@ -571,8 +571,23 @@ static bool launch_dw_direct(const DwArgs& a, int out, hipStream_t s) {
   if ((long)a.planes * a.h * a.w >= (1L << 31) || (long)a.planes * a.oh * a.ow >= (1L << 31)) return false;
   // rows per strip: amortise the 2-row halo while keeping many lanes (and bytes) in flight
   int rs;
-  if (a.sw == 1) rs = (a.oh % 8 == 0) ? 8 : (a.oh % 7 == 0 ? 7 : (a.oh >= 8 ? 8 : (a.oh >= 5 ? 7 : 4)));
-  else rs = (a.oh % 7 == 0 && a.oh <= 14) ? 7 : 4;
+  static int rs1_env = -1;
+  if (rs1_env < 0) {
+    const char* e = getenv("PLHIP_DW_RS1");
+    rs1_env = e ? atoi(e) : 0;
+  }
+  if (a.sw == 1 && (rs1_env == 4 || rs1_env == 7 || rs1_env == 8)) rs = rs1_env;
+  else if (a.sw == 1) rs = (a.oh % 8 == 0) ? 8 : (a.oh % 7 == 0 ? 7 : (a.oh >= 8 ? 8 : (a.oh >= 5 ? 7 : 4)));
+  else {
+    // stride 2 fetches 2 rows per output row: a taller strip amortises the per-row fetch / mask work (VALU-bound op)
+    static int rs2_env = -1;
+    if (rs2_env < 0) {
+      const char* e = getenv("PLHIP_DW_RS2");
+      rs2_env = e ? atoi(e) : 0;
+    }
+    if (rs2_env == 4 || rs2_env == 7 || rs2_env == 8) rs = rs2_env;
+    else rs = (a.oh % 7 == 0 && a.oh <= 14) ? 7 : 4;  // taller strips measured slower (dw3 33.7 -> 37.1 us): not VALU-bound
+  }
   const bool s1 = a.sw == 1;
   if (out == OUT_I32) s1 ? launch_dw_direct_s<OUT_I32, 1>(a, rs, s) : launch_dw_direct_s<OUT_I32, 2>(a, rs, s);
   else if (out == OUT_F32) s1 ? launch_dw_direct_s<OUT_F32, 1>(a, rs, s) : launch_dw_direct_s<OUT_F32, 2>(a, rs, s);

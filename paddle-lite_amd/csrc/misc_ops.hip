@@ -183,17 +183,7 @@ __global__ __launch_bounds__(256) void fc_i8_mfma_kernel(const int8_t* __restric
   const int mrow = mt * 32 + c < m ? mt * 32 + c : m - 1;
   const int8_t* xb = x + (size_t)mrow * k + 16 * h;
   const int8_t* ab = wfrag + (size_t)nt * KS * 1024 + lane * 16;
-  // scale / bias of the 4 features this lane finishes (register group = wave): issued first, consumed last
-  const int n0 = nt * 32 + 8 * wave + 4 * h;
-  float sc4[4] = {1.f, 1.f, 1.f, 1.f}, bi4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (OUT != OUT_I32) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sc4[e] = scale[n0 + e < n ? n0 + e : n - 1];
-    if (bias) {  // uniform
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bi4[e] = bias[n0 + e < n ? n0 + e : n - 1];
-    }
-  }
+  const int n0 = nt * 32 + 8 * wave + 4 * h;  // the 4 features this lane finishes (register group = wave)
   v16i acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0;
@@ -215,6 +205,16 @@ __global__ __launch_bounds__(256) void fc_i8_mfma_kernel(const int8_t* __restric
   // wave w finishes register group w: rows (features) nt*32 + 8w + 4h + (0..3), column (batch row) mt*32 + c
   const int mcol = mt * 32 + c;
   if (mcol >= m || n0 >= n) return;
+  // scale / bias: 8 independent loads issued together (hoisting them above the operand loads measured 6 us slower)
+  float sc4[4] = {1.f, 1.f, 1.f, 1.f}, bi4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (OUT != OUT_I32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sc4[e] = scale[n0 + e < n ? n0 + e : n - 1];
+    if (bias) {  // uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bi4[e] = bias[n0 + e < n ? n0 + e : n - 1];
+    }
+  }
   float f[4];
   int a4[4];
 #pragma unroll

@@ -236,7 +236,8 @@ const char* plhip_conv_impl_name(const plhip_conv_desc* d) {
   ConvGeom g;
   if (!conv_geom(d, &g)) return "invalid";
   if (g.impl == IMPL_GEMM_1X1) return "conv1x1s1_gemm_int8_mfma32x32x32";
-  if (g.impl == IMPL_DIRECT_3X3S2) return "conv_3x3s2_direct_int8_dot4";
+  if (g.impl == IMPL_DIRECT_3X3S2)  // one MFMA K-step when the taps fit (Cin <= 3, OW % 4 == 0), v_dot4 otherwise
+    return (d->cin * 3 <= 9 && (g.ow & 3) == 0) ? "conv_3x3s2_direct_int8_mfma32x32x32" : "conv_3x3s2_direct_int8_dot4";
   return "conv_im2col_gemm_int8_mfma32x32x32";
 }
 
