@@ -338,6 +338,9 @@ __device__ __forceinline__ void stem_mfma_body(const DirectS2Args& a, const int8
 
 template <int OUT, bool MFULL>
 __global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, const int8_t* __restrict__ afrag) {
+  PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias); PLHIP_PRELOAD(afrag);
+  PLHIP_PRELOAD(a.n); PLHIP_PRELOAD(a.cin); PLHIP_PRELOAD(a.h); PLHIP_PRELOAD(a.w); PLHIP_PRELOAD(a.cout); PLHIP_PRELOAD(a.oh);
+  PLHIP_PRELOAD(a.ow); PLHIP_PRELOAD(a.pt); PLHIP_PRELOAD(a.pl); PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha);
   __shared__ __attribute__((aligned(16))) float lsb_all[4][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -508,6 +508,10 @@ __device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, ui
 
 template <int OUT, int S, int RS, bool STAGE, bool FASTV>
 __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
+  PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.wt); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias);
+  PLHIP_PRELOAD(a.planes); PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.h); PLHIP_PRELOAD(a.w); PLHIP_PRELOAD(a.oh); PLHIP_PRELOAD(a.ow);
+  PLHIP_PRELOAD(a.pt); PLHIP_PRELOAD(a.pl); PLHIP_PRELOAD(a.total_lanes); PLHIP_PRELOAD(a.owq_log2); PLHIP_PRELOAD(a.spp_log2);
+  PLHIP_PRELOAD(a.fast_div); PLHIP_PRELOAD(a.stage_bytes); PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha);
   extern __shared__ __attribute__((aligned(16))) uint8_t dw_stage[];  // STAGE: 4 waves x stage_bytes
   long gid = (long)blockIdx.x * 256 + threadIdx.x;
   if (!STAGE && gid >= a.total_lanes) return;

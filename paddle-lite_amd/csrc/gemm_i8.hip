@@ -61,6 +61,10 @@ __device__ __forceinline__ void load_b(const int8_t* __restrict__ xb, int ks, in
 
 template <int MA, int OUT, bool VEC_STORE, bool MFULL, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
+  PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.x); PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias);
+  PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.K); PLHIP_PRELOAD(g.KS); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP);
+  PLHIP_PRELOAD(g.NB); PLHIP_PRELOAD(g.x_bstride); PLHIP_PRELOAD(g.y_bstride); PLHIP_PRELOAD(g.MT); PLHIP_PRELOAD(g.NT);
+  PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler too
   const long wid = (long)blockIdx.x * 4 + wave;
@@ -145,6 +149,10 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
 // register ring with static indices.
 template <int MA, int OUT, bool VEC_STORE, bool MFULL, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
+  PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.x); PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias);
+  PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.K); PLHIP_PRELOAD(g.KS); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP);
+  PLHIP_PRELOAD(g.NB); PLHIP_PRELOAD(g.x_bstride); PLHIP_PRELOAD(g.y_bstride); PLHIP_PRELOAD(g.MT); PLHIP_PRELOAD(g.NT);
+  PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg);
   __shared__ __attribute__((aligned(16))) v4i bs[2][4][4][64];  // [buf][kstep][i][lane] : 32 KiB
   __shared__ __attribute__((aligned(16))) float lsb_all[4][2 * MA * 32];
   const int lane = threadIdx.x & 63;
@@ -286,6 +294,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // GD_D = K-steps in flight (including the one being consumed); ring slots GD_NS = GD_D + 1.
 template <int MA, int OUT, bool VEC_STORE, bool MFULL, int GD_D>
 __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(GemmArgs g) {
+  PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.x); PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias);
+  PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.K); PLHIP_PRELOAD(g.KS); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP);
+  PLHIP_PRELOAD(g.NB); PLHIP_PRELOAD(g.x_bstride); PLHIP_PRELOAD(g.y_bstride); PLHIP_PRELOAD(g.MT); PLHIP_PRELOAD(g.NT);
+  PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg);
   constexpr int GD_NS = GD_D + 1;
   constexpr int SLOT = 4096 + 4 * MA * 1024;
   constexpr int PER = 1 + MA;  // DMA instructions per wave per K-step

@@ -63,4 +63,11 @@ __device__ __forceinline__ void transpose4x4_b8(uint32_t r0, uint32_t r1, uint32
   o3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
+
+// Kernel arguments live in memory (the kernarg segment); the compiler loads each field where it is first used, and a
+// branch between two uses turns that into SERIAL scalar-load round trips (timeline stamps: three of them, ~2300 cycles
+// before the first vector load of the GEMM kernel).  Naming a field here, at the top of a kernel, makes it live in
+// the entry block, so all fields arrive with one batch of s_load.
+#define PLHIP_PRELOAD(x) asm volatile("" ::"s"(x))
+
 }  // namespace plhip

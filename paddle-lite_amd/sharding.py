@@ -74,3 +74,46 @@ def all_gather_rows(local, dist, world):
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)
     return out
+
+
+class PipelinedGather:
+    """Result gather that never stalls the compute stream: step s stages its shard into buffer s % depth and starts an
+    asynchronous all_gather (RCCL runs it on its own stream, ordered after the staging copy); the buffer is only waited
+    for when it comes round again `depth` steps later, so the collective of step s overlaps the kernels of steps
+    s+1 .. s+depth-1.  `local_like` gives the shard shape / dtype / device."""
+
+    def __init__(self, local_like, dist, world, depth=2):
+        import torch
+        self.dist, self.world, self.depth = dist, world, depth
+        shape = tuple(local_like.shape)
+        self.local = [torch.empty_like(local_like) for _ in range(depth)]
+        self.out = [torch.empty((world * shape[0],) + shape[1:], dtype=local_like.dtype, device=local_like.device)
+                    for _ in range(depth)]
+        self.pending = [None] * depth
+        self.step = 0
+
+    def stage_buffer(self):
+        """Shard buffer of the current step (free: its previous collective has been waited for)."""
+        b = self.step % self.depth
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        return self.local[b]
+
+    def launch(self):
+        """Start the all_gather of the current step's staged shard; returns the [world*rows, ...] output tensor, which
+        is complete after drain() (or after this buffer's next stage_buffer())."""
+        b = self.step % self.depth
+        if self.world > 1:
+            self.pending[b] = self.dist.all_gather_into_tensor(self.out[b], self.local[b], async_op=True)
+        else:
+            self.out[b].copy_(self.local[b])
+        self.step += 1
+        return self.out[b]
+
+    def drain(self):
+        for b in range(self.depth):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+

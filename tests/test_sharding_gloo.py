@@ -36,6 +36,21 @@ lo, hi = sh.shard_range(8, rank, world)
 local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1).repeat(1, 3)
 g = sh.all_gather_rows(local, dist, world)
 assert g.shape == (8, 3) and torch.equal(g[:, 0], torch.arange(8, dtype=torch.float32))
+# pipelined gather (bench.py N > 1): 5 steps through 2 buffers, every step's result must be that step's shards
+pg = sh.PipelinedGather(local, dist, world, depth=2)
+outs = []
+for step in range(5):
+    buf = pg.stage_buffer()
+    buf.copy_(local + 100.0 * step)
+    outs.append((step, pg.launch()))
+    if step >= 1:  # the previous step's buffer is not reused before the next stage_buffer(): check it after a wait
+        pstep, pout = outs[-2]
+        h = pg.pending[pstep & 1]
+        if h is not None:
+            h.wait()
+        assert torch.equal(pout[:, 0], torch.arange(8, dtype=torch.float32) + 100.0 * pstep), (pstep, pout[:, 0])
+pg.drain()
+assert torch.equal(outs[-1][1][:, 0], torch.arange(8, dtype=torch.float32) + 400.0)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
