@@ -206,6 +206,53 @@ def test_mobilenet_layer_shapes_small_batch(gpu_ctx, pkg, plref):
     assert _check_all_kinds(gpu_ctx, capi, plref, 1, 3, 224, 224, 32, 3, 3, (1, 1, 1, 1), 2, 1, 1, 1, 0.0, True, rng) == 1
 
 
+def test_ring_gemm_column_space(gpu_ctx, pkg, plref):
+    """The LDS-DMA ring kernel (M > 192 or 96 < M <= 128, K >= 97): images are padded to 16 columns, the last 16-byte piece
+    of an image is end-aligned and its duplicate columns are skipped.  HW % 16 in {0, 1, 2, 4, 14}, HW % 4 != 0
+    (byte-unaligned pieces, partial-lane stores), M / K tails, batch not filling the last 128-column tile."""
+    rng = np.random.default_rng(110)
+    capi = pkg.capi
+    cnt = 0
+    for (h, w) in [(4, 4), (1, 17), (4, 5), (5, 6), (7, 7), (5, 10), (14, 14), (3, 11)]:
+        for (cin, cout) in [(128, 200), (130, 256), (97, 120), (160, 512)]:
+            act = (0, 1, 2, 4)[cnt % 4]
+            cnt += _check_all_kinds(gpu_ctx, capi, plref, 1 + cnt % 3, cin, h, w, cout, 1, 1, (0, 0, 0, 0), 1, 1, 1,
+                                    act, 6.0 if act == 2 else 0.3, cnt % 2 == 0, rng)
+    assert cnt == 32
+
+
+def test_stem_mfma_variants(gpu_ctx, pkg, plref):
+    """conv3x3s2 stem on the MFMA path (Cin <= 3, OW % 4 == 0): Cin 1/2/3, Cout tails and two M tiles, pads 0/1, more
+    than 32 quads per row (two column tiles), OH % 4 != 0 (partly empty row groups), several images; plus shapes that
+    must fall back to the dot4 kernel (OW % 4 != 0, Cin = 4)."""
+    rng = np.random.default_rng(111)
+    capi = pkg.capi
+    cnt = 0
+    for (n, cin, h, w, cout, pad) in [(1, 3, 16, 16, 32, 1), (2, 1, 18, 32, 8, 1), (3, 2, 9, 17, 40, 0), (1, 3, 21, 264, 64, 1),
+                                      (2, 3, 10, 8, 33, (0, 1, 1, 0)), (1, 3, 15, 15, 16, 1), (2, 4, 16, 16, 24, 1)]:
+        pads = (pad,) * 4 if isinstance(pad, int) else pad
+        act = (1, 0, 2, 4)[cnt % 4]
+        cnt += _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 3, 3, pads, 2, 1, 1, act, 6.0 if act == 2 else 0.2,
+                                cnt % 2 == 0, rng)
+    assert cnt == 7
+
+
+def test_dw_fast_fetch_and_staging(gpu_ctx, pkg, plref):
+    """depthwise 3x3 direct kernel: fast row fetch (pad <= 1, RS | OH) against the general fetch (pad 2, ragged OH), LDS
+    output staging for narrow planes with even / odd OW, partial last waves (plane count not a multiple of the wave's
+    strip count), first / last workgroup guards (single-plane tensors)."""
+    rng = np.random.default_rng(112)
+    capi = pkg.capi
+    cnt = 0
+    for st in (1, 2):
+        for (c, h, w, pad) in [(5, 14, 14, 1), (37, 7, 7, 1), (3, 28, 28, 1), (1, 56, 56, 1), (9, 16, 12, 0), (4, 14, 14, 2),
+                               (130, 14, 14, 1), (2, 112, 112, 1), (6, 8, 30, 1)]:
+            act = (1, 2, 0, 4)[cnt % 4]
+            cnt += _check_all_kinds(gpu_ctx, capi, plref, 1 + cnt % 2, c, h, w, c, 3, 3, (pad,) * 4, st, 1, c, act,
+                                    6.0 if act == 2 else 0.3, cnt % 2 == 0, rng, depthwise=True)
+    assert cnt == 18
+
+
 def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
     capi = pkg.capi
     g = load_golden(golden_files("fc_")[0])
