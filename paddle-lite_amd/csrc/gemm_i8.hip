@@ -292,15 +292,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // GD_D = K-steps in flight (including the one being consumed); ring slots GD_NS = GD_D + 1.
-template <int MA, int OUT, bool VEC_STORE, bool MFULL, int GD_D>
+// AREG: the A fragments go straight from L2 into a 4-deep REGISTER ring (they are already in fragment order in memory) and
+// never touch LDS: per block and K-step the LDS sees 20 KB (4 KB of B written once, read by 4 waves) instead of 36 KB --
+// with two blocks per CU the old traffic alone (72 KB / 128 B per clock = 562 cycles) exceeded the MFMA time of a K-step
+// pair (512).  Needs KS % 4 == 0 (static register names: the loop is unrolled by the ring size).
+// NG = KS / 4 as a template constant: the K loop is then straight-line code.  With a loop back-edge the compiler cannot
+// count the vector-memory operations in flight and protects the loop-carried fragment registers with s_waitcnt vmcnt(0)
+// at the top of every group, which drains the whole pipeline.  NG == 0: A through LDS (any KS).
+template <int MA, int OUT, bool VEC_STORE, bool MFULL, int GD_D, int NG>
 __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(GemmArgs g) {
+  constexpr bool AREG = NG > 0;
   PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.x); PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias);
   PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.K); PLHIP_PRELOAD(g.KS); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP);
   PLHIP_PRELOAD(g.NB); PLHIP_PRELOAD(g.x_bstride); PLHIP_PRELOAD(g.y_bstride); PLHIP_PRELOAD(g.MT); PLHIP_PRELOAD(g.NT);
   PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg);
   constexpr int GD_NS = GD_D + 1;
-  constexpr int SLOT = 4096 + 4 * MA * 1024;
-  constexpr int PER = 1 + MA;  // DMA instructions per wave per K-step
+  constexpr int SLOT = AREG ? 4096 : 4096 + 4 * MA * 1024;
+  constexpr int PER = 1 + MA;  // vector-memory instructions per wave per K-step (1 B piece + MA A fragments)
   extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // GD_NS * SLOT ring + 4 waves x scale/bias (ONE LDS object)
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -360,9 +368,25 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
     int k = ks * 32 + prow;
     k = k < g.K ? k : g.K - 1;  // rows past K meet zero-padded weights
     __builtin_amdgcn_global_load_lds((glb_ptr)(xb + (size_t)k * g.XP), (lds_ptr)(sb + wave * 1024), 16, 0, 0);
+    if (!AREG) {
 #pragma unroll
-    for (int a = 0; a < MA; ++a)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(ab + ((size_t)a * KS + ks) * 1024), (lds_ptr)(sb + 4096 + (wave * MA + a) * 1024), 16, 0, 0);
+      for (int a = 0; a < MA; ++a)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(ab + ((size_t)a * KS + ks) * 1024), (lds_ptr)(sb + 4096 + (wave * MA + a) * 1024), 16, 0, 0);
+    }
+  };
+  // AREG: fragment order in memory == register layout.  The load is issued through inline asm ON PURPOSE: next to LDS-DMA
+  // operations the compiler's wait-count pass protects every register written by an ordinary load with
+  // s_waitcnt vmcnt(0) (seen in the ISA even in straight-line code), which would drain the whole DMA pipeline at each
+  // first use.  The asm load is invisible to that pass; the counted waits of the pipeline (wait_vmcnt, in-order vmcnt)
+  // already guarantee that K-step ks's fragments have arrived one iteration before they are multiplied.  The price is a
+  // build-time obligation: no register copy of an in-flight fragment may be inserted between the load and its MFMAs --
+  // the parity suite (random operands) fails on any such copy, and tools/check_areg_isa.py checks the ISA.
+  auto load_a_regs = [&](int ks, v4i (&dst)[MA]) {
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+      const int8_t* p = ab + ((size_t)a * KS + ks) * 1024;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[a]) : "v"(p) : "memory");
+    }
   };
 
   // ---- pipeline ----
@@ -377,8 +401,13 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   constexpr int AHEAD = GD_D;
   // prologue: K-steps 0 .. AHEAD-1 in flight (the launcher guarantees KS >= AHEAD); the accumulators are zeroed
   // behind the issue, while the first bytes travel
+  v4i aring[AREG ? 4 : 1][MA];
+  static_assert(!AREG || GD_D == 4, "the register ring is as deep as the DMA look-ahead");
 #pragma unroll
-  for (int p = 0; p < AHEAD; ++p) issue(p, p);
+  for (int p = 0; p < AHEAD; ++p) {
+    issue(p, p);
+    if (AREG) load_a_regs(p, aring[AREG ? p : 0]);
+  }
   float my_s = 1.f, my_b = 0.f;
   if (OUT != OUT_I32) load_scale_bias<MA>(g, mtc, lane, my_s, my_b);  // 2 more vmcnt entries, younger than the prologue DMA
   __builtin_amdgcn_sched_barrier(0);
@@ -394,8 +423,10 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
     const uint8_t* sb = ring + slot * SLOT;
 #pragma unroll
     for (int j = 0; j < 16; ++j) raw[j] = *reinterpret_cast<const uint32_t*>(sb + (16 * h + j) * 128 + 4 * c);
+    if (!AREG) {
 #pragma unroll
-    for (int a = 0; a < MA; ++a) af[a] = *reinterpret_cast<const v4i*>(sb + 4096 + (wave * MA + a) * 1024 + lane * 16);
+      for (int a = 0; a < MA; ++a) af[a] = *reinterpret_cast<const v4i*>(sb + 4096 + (wave * MA + a) * 1024 + lane * 16);
+    }
   };
   auto transpose = [&](const uint32_t (&raw)[16], v4i (&bf)[4]) {
 #pragma unroll
@@ -412,8 +443,10 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   PLHIP_STAMP(3);
   uint32_t raw[16];
   v4i af_cur[MA], af_nxt[MA], bf_cur[4], bf_nxt[4];
-  // K-step 0 into registers: AHEAD-1 younger K-steps of PER pieces each, plus the scale / bias loads
-  wait_vmcnt<(AHEAD - 1) * PER + (OUT != OUT_I32 ? 2 : 0)>();
+  // K-step 0 into registers: AHEAD-1 younger K-steps of PER pieces each.  The scale / bias loads behind them are NOT
+  // counted: there are 0, 1 or 2 of them (no bias pointer, int32 output), and a count that is too high by one lets the
+  // wave run ahead of its own last piece (seen as an intermittent wrong 32-row tile); too low only waits a little longer.
+  wait_vmcnt<(AHEAD - 1) * PER>();
   __builtin_amdgcn_s_barrier();
   read_slot(0, raw, af_cur);
   transpose(raw, bf_cur);
@@ -421,16 +454,22 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   // one iteration; YOUNGER = my K-steps issued after ks+1 that may still be in flight at the wait, ISSUE / NEXT: whether
   // K-step ks+AHEAD / ks+1 exists (compile-time in the steady state and in the peeled tail)
   int rslot = 1, islot = AHEAD % GD_NS;
-  auto step = [&](int ks, auto younger_c, auto issue_c, auto next_c) {
+  auto step = [&](int ks, auto younger_c, auto issue_c, auto next_c, auto ring_c) {
+    constexpr int RI = AREG ? decltype(ring_c)::value : 0;  // AREG: K-step ks lives in aring[ks % 4]
     constexpr int YOUNGER = decltype(younger_c)::value;
     constexpr bool ISSUE = decltype(issue_c)::value;
     constexpr bool NEXT = decltype(next_c)::value;
     if (ks < STAMP_SLOTS - 8) PLHIP_STAMP(4 + ks);
+    const bool sub = diag && (g.dbg & 64) && ks == 6;  // sub-stamps of one steady-state K-step (they perturb it: the
+                                                        // s_memtime results force lgkmcnt(0), i.e. wait for the LDS reads)
     if (NEXT) {
       wait_vmcnt<YOUNGER * PER>();
+      if (sub && lane == 0) lstamp[20] = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();  // K-step ks+1 complete for everyone; nobody reads K-step ks-1's slot any more
+      if (sub && lane == 0) lstamp[21] = __builtin_amdgcn_s_memtime();
       read_slot(rslot, raw, af_nxt);
       rslot = rslot + 1 == GD_NS ? 0 : rslot + 1;
+      if (sub && lane == 0) lstamp[22] = __builtin_amdgcn_s_memtime();
     }
     if (ISSUE) {
       issue(ks + AHEAD, islot);
@@ -439,45 +478,72 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
 #pragma unroll
     for (int a = 0; a < MA; ++a)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur[a], bf_cur[i], acc[a][i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AREG ? aring[RI][a] : af_cur[a], bf_cur[i], acc[a][i], 0, 0, 0);
     if (NEXT) transpose(raw, bf_nxt);
-    // schedule: [MFMA + one DMA piece] x PER, then the remaining MFMAs share the transposes
+    // schedule: [MFMA + one DMA piece] x (pieces issued here), bare MFMAs, then the remaining MFMAs share the transposes
     constexpr int NM = 4 * MA;
+    constexpr int NDMA = AREG ? 1 : PER;  // LDS-DMA pieces issued among the first MFMAs
+    constexpr int LEAD = PER;             // MFMAs in front of the first transpose (LDS read latency)
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
+    for (int q = 0; q < LEAD; ++q) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (ISSUE) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // address arithmetic of the piece
-      if (ISSUE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      if (ISSUE && q < NDMA) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // address arithmetic of the piece
+      if (ISSUE && q < NDMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
     }
 #pragma unroll
-    for (int q = PER; q < NM; ++q) {
+    for (int q = LEAD; q < NM; ++q) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, (32 + NM - PER - 1) / (NM - PER), 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, (32 + NM - LEAD - 1) / (NM - LEAD), 0);
     }
+    if (sub && lane == 0) lstamp[23] = __builtin_amdgcn_s_memtime();
+    // AREG: the fragments of K-step ks+AHEAD replace the ones just consumed.  At the END of the step: an asm statement
+    // closes the scheduling region, and the MFMA / v_perm interleave above must stay in one region.
+    if (AREG && ISSUE) load_a_regs(ks + AHEAD, aring[RI]);
     if (NEXT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) bf_cur[i] = bf_nxt[i];
+      if (!AREG) {
 #pragma unroll
-      for (int a = 0; a < MA; ++a) af_cur[a] = af_nxt[a];
+        for (int a = 0; a < MA; ++a) af_cur[a] = af_nxt[a];
+      }
     }
   };
   using std::integral_constant;
-  const int kmain = (g.dbg & 2) ? 0 : KS - AHEAD;
-  for (int ks = 0; ks < kmain; ++ks)
-    step(ks, integral_constant<int, AHEAD - 2>{}, integral_constant<bool, true>{}, integral_constant<bool, true>{});
-  if (!(g.dbg & 2)) {
-    // peeled tail: K-steps KS-AHEAD .. KS-1, nothing left to issue, the in-flight count shrinks
-    static_assert(AHEAD >= 2 && AHEAD <= 8, "tail is written for 2..8 K-steps ahead");
-    int ks = KS - AHEAD;
-#define PLHIP_TAIL(T)                                                                                              \
-  if (AHEAD - 1 > T) {                                                                                             \
-    step(ks, integral_constant<int, (AHEAD - 2 - T > 0 ? AHEAD - 2 - T : 0)>{}, integral_constant<bool, false>{},  \
-         integral_constant<bool, true>{});                                                                         \
-    ++ks;                                                                                                          \
+  typedef integral_constant<bool, true> T_;
+  typedef integral_constant<bool, false> F_;
+  if (AREG) {
+    // unrolled by the ring size: K-step ks uses aring[ks % 4]; KS == 4 * NG, so the last group is the peeled tail
+    if (!(g.dbg & 2)) {
+      int ks = 0;
+#pragma unroll
+      for (int gi = 0; gi + 1 < NG; ++gi, ks += 4) {
+        step(ks, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 0>{});
+        step(ks + 1, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 1>{});
+        step(ks + 2, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 2>{});
+        step(ks + 3, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 3>{});
+      }
+      step(ks, integral_constant<int, 2>{}, F_{}, T_{}, integral_constant<int, 0>{});
+      step(ks + 1, integral_constant<int, 1>{}, F_{}, T_{}, integral_constant<int, 1>{});
+      step(ks + 2, integral_constant<int, 0>{}, F_{}, T_{}, integral_constant<int, 2>{});
+      step(ks + 3, integral_constant<int, 0>{}, F_{}, F_{}, integral_constant<int, 3>{});
+    }
+  } else {
+    const int kmain = (g.dbg & 2) ? 0 : KS - AHEAD;
+    for (int ks = 0; ks < kmain; ++ks) step(ks, integral_constant<int, AHEAD - 2>{}, T_{}, T_{}, integral_constant<int, 0>{});
+    if (!(g.dbg & 2)) {
+      // peeled tail: K-steps KS-AHEAD .. KS-1, nothing left to issue, the in-flight count shrinks
+      static_assert(AHEAD >= 2 && AHEAD <= 8, "tail is written for 2..8 K-steps ahead");
+      int ks = KS - AHEAD;
+#define PLHIP_TAIL(T)                                                                                                    \
+  if (AHEAD - 1 > T) {                                                                                                   \
+    step(ks, integral_constant<int, (AHEAD - 2 - T > 0 ? AHEAD - 2 - T : 0)>{}, F_{}, T_{}, integral_constant<int, 0>{}); \
+    ++ks;                                                                                                                \
   }
-    PLHIP_TAIL(0) PLHIP_TAIL(1) PLHIP_TAIL(2) PLHIP_TAIL(3) PLHIP_TAIL(4) PLHIP_TAIL(5) PLHIP_TAIL(6)
+      PLHIP_TAIL(0) PLHIP_TAIL(1) PLHIP_TAIL(2) PLHIP_TAIL(3) PLHIP_TAIL(4) PLHIP_TAIL(5) PLHIP_TAIL(6)
 #undef PLHIP_TAIL
-    step(ks, integral_constant<int, 0>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+      step(ks, integral_constant<int, 0>{}, F_{}, F_{}, integral_constant<int, 0>{});
+    }
   }
 
   if (OUT != OUT_I32) store_scale_bias<MA, OUT>(lsb, lane, my_s, my_b);
@@ -766,17 +832,36 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
   if (use_dma) {
     g.NT = (int)(((long)g.NB * ((g.HWX + 15) & ~15) + 127) / 128);  // 16-byte padded column space of this kernel
     const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
-    const size_t lds = (size_t)(4 + 1) * (4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4 + 4 * STAMP_SLOTS * 8;
-#define PLHIP_LAUNCH_DMA(VS, MF)                                                                                  \
+    static int areg_env = -1;
+    if (areg_env < 0) {
+      const char* e = getenv("PLHIP_GEMM_AREG");
+      areg_env = e ? atoi(e) : 1;
+    }
+    const int ng = (areg_env && (g.KS & 3) == 0 && mfull && MA == 2) ? g.KS >> 2 : 0;
+    const bool areg = ng == 1 || ng == 2 || ng == 4 || ng == 8;  // K = 128 / 256 / 512 / 1024
+    const size_t lds = (size_t)(4 + 1) * (areg ? 4096 : 4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4 + 4 * STAMP_SLOTS * 8;
+#define PLHIP_LAUNCH_DMA2(VS, MF, NGV)                                                                            \
   do {                                                                                                            \
-    auto kfn = gemm_i8_dma_kernel<MA, OUT, VS, MF, 4>;                                                            \
+    auto kfn = gemm_i8_dma_kernel<MA, OUT, VS, MF, 4, NGV>;                                                       \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, s, g);                                                  \
+  } while (0)
+#define PLHIP_LAUNCH_DMA(VS, MF)                                            \
+  do {                                                                      \
+    if (MA == 2 && MF && areg) {                                            \
+      if (ng == 1) PLHIP_LAUNCH_DMA2(VS, MF, (MA == 2 && MF) ? 1 : 0);      \
+      else if (ng == 2) PLHIP_LAUNCH_DMA2(VS, MF, (MA == 2 && MF) ? 2 : 0); \
+      else if (ng == 4) PLHIP_LAUNCH_DMA2(VS, MF, (MA == 2 && MF) ? 4 : 0); \
+      else PLHIP_LAUNCH_DMA2(VS, MF, (MA == 2 && MF) ? 8 : 0);              \
+    } else {                                                                \
+      PLHIP_LAUNCH_DMA2(VS, MF, 0);                                         \
+    }                                                                       \
   } while (0)
     if (vec_store && mfull) PLHIP_LAUNCH_DMA(true, true);
     else if (vec_store) PLHIP_LAUNCH_DMA(true, false);
     else if (mfull) PLHIP_LAUNCH_DMA(false, true);
     else PLHIP_LAUNCH_DMA(false, false);
+#undef PLHIP_LAUNCH_DMA2
 #undef PLHIP_LAUNCH_DMA
     return;
   }

@@ -77,6 +77,12 @@ def main():
             for i in range(min(ks, SLOTS - 8) - 1):
                 show("K-step %d" % i, t[:, 5 + i] - t[:, 4 + i])
             lastk = 4 + min(ks, SLOTS - 8) - 1
+            if int(os.environ.get("PLHIP_GEMM_DEBUG", "0")) & 64:
+                show("  K-step 6: top -> vmcnt wait done", t[:, 20] - t[:, 10])
+                show("  K-step 6: barrier", t[:, 21] - t[:, 20])
+                show("  K-step 6: LDS reads issued + returned", t[:, 22] - t[:, 21])
+                show("  K-step 6: DMA issue + MFMAs + perms", t[:, 23] - t[:, 22])
+                show("  K-step 6: end -> next top", t[:, 11] - t[:, 23])
             show("last K-step -> loop end", t[:, SLOTS - 4] - t[:, lastk])
             show("whole loop", t[:, SLOTS - 4] - t[:, 4])
             show("epilogue issue", t[:, SLOTS - 3] - t[:, SLOTS - 4])
