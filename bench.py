@@ -113,11 +113,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal on a one-GPU box (never used by the driver): PLHIP_BENCH_SAME_GPU=1 puts every rank on device 0 and
+    # PLHIP_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so that the N > 1 control flow
+    # (weight broadcast, staging copies, pipelined gather, max-over-ranks timing) can be exercised end to end.
+    if os.environ.get("PLHIP_BENCH_SAME_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("PLHIP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- weights: rank 0 generates, RCCL broadcast over xGMI, every rank builds its predictor from the bytes ----
     W = wl.make_mobilenet_v1_weights(seed=1234) if rank == 0 else None
