@@ -1,18 +1,23 @@
 #!/bin/bash
 # Collects the round's measurement evidence on the GPU box (run through gpurun from the repo root):
-#   kernel-trace stats of bench.py, FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, kernel-trace only), the per-layer
-#   table, the GEMM timeline, and a plain bench line.  Everything lands in gpurun_out/evidence/.
+#   kernel-trace stats of bench.py (default command = 3 steps in flight, and the serial form whose per-kernel times are the
+#   ones behind `roofline`), FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, kernel-trace only, serial form), the
+#   per-layer table, the GEMM timeline, and plain bench lines.  Everything lands in gpurun_out/evidence/.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/evidence
-mkdir -p $O
+rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o p --output-format csv -- python $R/bench.py --no-cpu-baseline --steps 30 > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/fetch.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/write.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_default -o p --output-format csv -- python $R/bench.py --no-cpu-baseline --steps 30 > $O/bench_under_rocprof_default.json 2> $O/stats_default.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_serial -o p --output-format csv -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 30 > $O/bench_under_rocprof_serial.json 2> $O/stats_serial.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 3 --warmup 1 > /dev/null 2> $O/fetch.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 3 --warmup 1 > /dev/null 2> $O/write.err || exit 1
 cd $R
 timeout -k 10 200 python tools/opbench.py all 2>&1 | cut -c1-110 | grep -v fused > $O/opbench.txt || exit 1
 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/gemm_timeline.py pw8 > $O/gemm_timeline_pw8.txt 2>&1 || exit 1
 timeout -k 10 400 python bench.py --layer-table > $O/bench.json 2> $O/layer_table.txt || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_inflight1.json 2>/dev/null || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 2 > $O/bench_inflight2.json 2>/dev/null || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 4 > $O/bench_inflight4.json 2>/dev/null || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --streams 2 > $O/bench_streams2.json 2>/dev/null || exit 1
-tail -c 400 $O/bench.json
+tail -c 300 $O/bench.json
