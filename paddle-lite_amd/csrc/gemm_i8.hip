@@ -37,6 +37,20 @@ namespace plhip {
 // 7x7 layers, or a misaligned base) the dwords are read unaligned — legal for global memory on gfx950 — and the one
 // dword that would cross the end of the tensor is assembled bytewise.  Columns >= HW of a 4-column group then hold
 // bytes of the next row: harmless, a GEMM column only ever feeds its own (discarded) output column.
+// XCD-aware tile map of the shared-B kernels.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so
+// block b runs on XCD b % 8.  (1) The mtb_n blocks that share one B tile get ids equal mod 8 and adjacent in dispatch
+// order: the tile crosses the fabric once instead of mtb_n times (FETCH_SIZE was 3.4x the algorithmic bytes on the M = 512
+// layers).  (2) Each XCD owns a CONTIGUOUS range of N tiles: a tile's 128-byte row segments are not cache-line aligned
+// (row pitch HW = 196, 784, 3136 ...), so neighbouring tiles share most of their cache lines; with neighbours on
+// different XCDs every such line was fetched twice (FETCH x2 was still 2.2-2.4x the input bytes after (1)).
+__device__ __forceinline__ void xcd_tile_map(int b, int mtb_n, int NT, int& mtb, int& nt) {
+  const int ntx = (NT + 7) >> 3;  // N tiles per XCD
+  const int x = b & 7, q = b >> 3;
+  const int j = q / mtb_n;
+  mtb = q - j * mtb_n;
+  nt = x * ntx + j;  // >= NT for the padding blocks of the last XCDs: callers return
+}
+
 template <bool ALIGNED>
 __device__ __forceinline__ void load_b(const int8_t* __restrict__ xb, int ks, int h, int K, int XP, long room, uint32_t (&raw)[16]) {
 #pragma unroll
@@ -161,9 +175,8 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
   // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the mtb_n blocks that
   // share one B tile get ids that are equal mod 8 (same XCD, adjacent in dispatch order): the tile crosses the fabric
   // once instead of mtb_n times (PMC: FETCH_SIZE was 3.4x the algorithmic bytes on the M = 512 layers).
-  const int grp = blockIdx.x / (8 * mtb_n), rem = blockIdx.x - grp * (8 * mtb_n);
-  const int mtb = rem >> 3;
-  const int nt = grp * 8 + (rem & 7);
+  int mtb, nt;
+  xcd_tile_map(blockIdx.x, mtb_n, g.NT, mtb, nt);
   if (nt >= g.NT) return;  // block-uniform (grid is padded to 8 N-tiles)
   const int mt = mtb * 4 + wave;
   const bool mactive = mt < g.MT;  // wave-uniform; inactive waves still load their share of B and hit the barriers
@@ -318,9 +331,8 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the mtb_n blocks that
   // share one B tile get ids that are equal mod 8 (same XCD, adjacent in dispatch order): the tile crosses the fabric
   // once instead of mtb_n times (PMC: FETCH_SIZE was 3.4x the algorithmic bytes on the M = 512 layers).
-  const int grp = blockIdx.x / (8 * mtb_n), rem = blockIdx.x - grp * (8 * mtb_n);
-  const int mtb = rem >> 3;
-  const int nt = grp * 8 + (rem & 7);
+  int mtb, nt;
+  xcd_tile_map(blockIdx.x, mtb_n, g.NT, mtb, nt);
   if (nt >= g.NT) return;  // block-uniform (grid is padded to 8 N-tiles)
   const int mt = mtb * 4 + wave;
   const bool mactive = mt < g.MT;
@@ -597,9 +609,8 @@ __global__ __launch_bounds__(384, 2) void gemm_i8_ws_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mtb_n = (g.MT + 3) >> 2;
-  const int grp = blockIdx.x / (8 * mtb_n), rem = blockIdx.x - grp * (8 * mtb_n);
-  const int mtb = rem >> 3;
-  const int nt = grp * 8 + (rem & 7);
+  int mtb, nt;
+  xcd_tile_map(blockIdx.x, mtb_n, g.NT, mtb, nt);
   if (nt >= g.NT) return;  // block-uniform
   const int c = lane & 31, h = lane >> 5;
   const int ntot = g.NB * g.HWX;
