@@ -229,15 +229,15 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(DirectS2Args a) {
 // few bytes after the tensor); all others read the window from its true start column and mask.
 template <int OUT, bool MFULL, bool GUARD>
 __device__ __forceinline__ void stem_mfma_body(const DirectS2Args& a, const int8_t* __restrict__ afrag, float* lsb, int lane,
-                                               int wave) {
-  // grid = (quad tiles of a row, groups of 4 output rows, images): the image, the output row and with them every row
-  // offset / validity are wave-uniform (SALU); only the quad index is per lane.  No integer division anywhere.
+                                               int wave, int bx, int by, int bz) {
+  // block = (quad tile of a row, group of 4 output rows, image), decoded by the kernel from a 1-D XCD-contiguous id: the
+  // image, the output row and with them every row offset / validity are wave-uniform; only the quad index is per lane.
   const int c = lane & 31, h = lane >> 5;
   const int owq = a.ow >> 2;  // OW % 4 == 0 here
-  const int b = blockIdx.z;
-  const int oy = blockIdx.y * 4 + wave;
+  const int b = bz;
+  const int oy = by * 4 + wave;
   if (oy >= a.oh) return;  // wave-uniform; no barrier in this kernel
-  int xq = blockIdx.x * 32 + c;
+  int xq = bx * 32 + c;
   const bool qvalid = xq < owq;
   if (!qvalid) xq = owq - 1;
   const int start = 8 * xq - a.pl;
@@ -345,10 +345,19 @@ __global__ __launch_bounds__(256) void conv3x3s2_mfma_kernel(DirectS2Args a, con
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* lsb = lsb_all[wave];
+  // 1-D grid of 8 * per blocks; XCD x (= blockIdx % 8, round-robin dispatch) gets the x-th eighth of the (image, row
+  // group, column tile) space, so that row groups sharing an input row sit on one L2.  All of it is wave-uniform.
+  const int nx = ((a.ow >> 2) + 31) >> 5, ny = (a.oh + 3) >> 2;
+  const unsigned nb = (unsigned)(nx * ny * a.n), per = (nb + 7) >> 3;
+  const unsigned vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (vb >= nb) return;
+  const int bx = (int)(vb % (unsigned)nx);
+  const unsigned t = vb / (unsigned)nx;
+  const int by = (int)(t % (unsigned)ny), bz = (int)(t / (unsigned)ny);
   // only the first rows of the first image / the last rows of the last image can touch bytes outside the tensor
-  const bool guard = (blockIdx.z == 0 && blockIdx.y == 0) || (blockIdx.z + 1 == gridDim.z && blockIdx.y + 1 == gridDim.y);
-  if (guard) stem_mfma_body<OUT, MFULL, true>(a, afrag, lsb, lane, wave);
-  else stem_mfma_body<OUT, MFULL, false>(a, afrag, lsb, lane, wave);
+  const bool guard = (bz == 0 && by == 0) || (bz + 1 == a.n && by + 1 == ny);
+  if (guard) stem_mfma_body<OUT, MFULL, true>(a, afrag, lsb, lane, wave, bx, by, bz);
+  else stem_mfma_body<OUT, MFULL, false>(a, afrag, lsb, lane, wave, bx, by, bz);
 }
 
 // A fragments: tile mt, lane (r = lane&31, h = lane>>5), byte j  <-  W[mt*32 + r][window cr = 5h + j/3][tap j%3]
@@ -383,8 +392,9 @@ void launch_conv3x3s2_direct(const DirectS2Args& a, int out, hipStream_t s) {
   const long tensor = (long)a.n * a.cin * a.h * a.w;
   const int owq = a.ow >> 2;
   if (mfma_env && a.cin * 3 <= 9 && (a.ow & 3) == 0 && ((uintptr_t)a.y & (4 * esz - 1)) == 0 && tensor < (1L << 31) &&
-      8 * (owq - 1) - a.pl < a.w && a.n <= 65535 && (a.oh + 3) / 4 <= 65535) {
-    const dim3 blocks((unsigned)((owq + 31) / 32), (unsigned)((a.oh + 3) / 4), (unsigned)a.n);
+      8 * (owq - 1) - a.pl < a.w && (long)((owq + 31) / 32) * ((a.oh + 3) / 4) * a.n < (1L << 31) - 8) {
+    const long nblk = (long)((owq + 31) / 32) * ((a.oh + 3) / 4) * a.n;
+    const dim3 blocks((unsigned)((nblk + 7) / 8 * 8));
     const int8_t* afrag = reinterpret_cast<const int8_t*>(a.wp) + ds2_dot4_bytes(a.cin, a.cout);
     const bool mfull = a.cout % 32 == 0;
 #define PLHIP_STEM(O)                                                                                       \

@@ -513,15 +513,21 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
   PLHIP_PRELOAD(a.pt); PLHIP_PRELOAD(a.pl); PLHIP_PRELOAD(a.total_lanes); PLHIP_PRELOAD(a.owq_log2); PLHIP_PRELOAD(a.spp_log2);
   PLHIP_PRELOAD(a.fast_div); PLHIP_PRELOAD(a.stage_bytes); PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha);
   extern __shared__ __attribute__((aligned(16))) uint8_t dw_stage[];  // STAGE: 4 waves x stage_bytes
-  long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  // XCD-contiguous work: workgroups are dealt round-robin over the 8 XCDs (private L2 each); giving XCD x the x-th eighth
+  // of the lane space keeps neighbouring strips (which share their 2 halo rows and the cache lines at their edges) on
+  // one L2 (PMC: FETCH x2 was 1.3x the input bytes with consecutive blocks on consecutive XCDs).  grid = 8 * per blocks.
+  const unsigned nb = (unsigned)((a.total_lanes + 255) >> 8), per = (nb + 7) >> 3;
+  const unsigned vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (vb >= nb) return;
+  long gid = (long)vb * 256 + threadIdx.x;
   if (!STAGE && gid >= a.total_lanes) return;
   // STAGE: lanes past the end stay (they help with the cooperative copy-out) but are wave-uniformly dropped when the
   // whole wave is past the end; a dead lane recomputes the last live quad and skips its LDS writes
   if (STAGE && gid - (threadIdx.x & 63) >= a.total_lanes) return;
   uint8_t* wlds = STAGE ? dw_stage + (threadIdx.x >> 6) * a.stage_bytes : nullptr;
   // only the last workgroups can touch the final bytes of the tensor: they alone pay for the guarded loads
-  if (blockIdx.x + 4 >= gridDim.x) dw3x3_direct_body<OUT, S, RS, true, STAGE>(a, gid, wlds);
-  else if (FASTV && blockIdx.x != 0) dw3x3_fast_body<OUT, S, RS, STAGE>(a, gid, wlds);
+  if (vb + 4 >= nb) dw3x3_direct_body<OUT, S, RS, true, STAGE>(a, gid, wlds);
+  else if (FASTV && vb != 0) dw3x3_fast_body<OUT, S, RS, STAGE>(a, gid, wlds);
   else dw3x3_direct_body<OUT, S, RS, false, STAGE>(a, gid, wlds);
 }
 
@@ -530,7 +536,7 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
   const long owq = (a_in.ow + 3) >> 2;
   const long spp = (a_in.oh + rs - 1) / rs;
   const long total = (long)a_in.planes * spp * owq;
-  const unsigned blocks = (unsigned)((total + 255) / 256);
+  const unsigned blocks = (unsigned)(((total + 255) / 256 + 7) / 8 * 8);  // 8 XCDs x equal shares (kernel: vb map)
   DwArgs a = a_in;
   a.total_lanes = total;
   auto lg2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return (1L << l) == v ? l : -1; };
