@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Copy the evidence bundle of tools/collect_evidence.sh (gpurun_out/evidence/) into profiles/ under the round's names,
+aggregate the PMC passes per kernel, regenerate profiles/pmc_traffic.json and print the numbers DESIGN.md quotes.
+Usage: python tools/update_profiles.py [round_tag=r01]"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E = os.path.join(ROOT, "gpurun_out", "evidence")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def cp(src, dst):
+    shutil.copyfile(os.path.join(E, src), os.path.join(P, "%s_final_%s" % (tag, dst)))
+
+
+cp("stats_serial/p_kernel_stats.csv", "kernel_stats_serial.csv")
+cp("stats_default/p_kernel_stats.csv", "kernel_stats_default.csv")
+cp("opbench.txt", "opbench.txt")
+cp("layer_table.txt", "layer_table.txt")
+cp("bench.json", "bench.json")
+cp("bench_inflight1.json", "bench_inflight1.json")
+cp("gemm_timeline_pw8.txt", "gemm_timeline_pw8.txt")
+for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob(os.path.join(E, kind, "*_counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            a = agg[r["Kernel_Name"][:90]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    with open(os.path.join(P, "%s_final_pmc_%s_size.csv" % (tag, kind)), "w") as o:
+        o.write("kernel,dispatches,%s_sum_KiB,%s_per_dispatch_KiB\n" % (counter, counter))
+        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            o.write('"%s",%d,%.1f,%.1f\n' % (k, n, v, v / n))
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(E, "fetch"),
+                       os.path.join(E, "write"), os.path.join(P, "pmc_traffic.json")], stdout=subprocess.DEVNULL)
+
+
+def g(f):
+    return json.loads(open(os.path.join(E, f)).read().strip().splitlines()[-1])
+
+
+for f in ("bench.json", "bench_inflight1.json", "bench_inflight2.json", "bench_inflight4.json", "bench_streams2.json"):
+    d = g(f)
+    print("%-24s %9.1f img/s  %.4f ms/step  roofline.frac %.4f" % (f, d["value"], d["ms_per_step"], d["roofline"]["frac"]))
+print(open(os.path.join(P, "%s_final_opbench.txt" % tag)).read().splitlines()[-1])
+print(json.dumps(json.load(open(os.path.join(P, "pmc_traffic.json")))["pointwise1x1"]))
