@@ -67,3 +67,34 @@ def test_round_half_away_integer_trick(plref):
     assert np.array_equal(q[:5000], ref)
     # vectorised check of the rest through the calib oracle (scale 1 => q = round_sat(y))
     assert np.array_equal(q, plref.calib_f32_to_i8(y, 1.0).astype(np.int32))
+
+
+def test_xcd_contiguous_maps_cover_every_tile_once():
+    """Host mirror of the device-side work maps (csrc/gemm_i8.hip xcd_tile_map, the vb maps of the depthwise / stem
+    kernels): block b runs on XCD b % 8 and takes the (b % 8)-th eighth of the work; every tile / virtual block must be
+    visited exactly once, the padding blocks must fall outside, and the blocks sharing a B tile must sit on one XCD."""
+    for mtb_n in (1, 2, 3, 4):
+        for NT in (1, 7, 8, 9, 64, 196, 197, 203):
+            ntx = (NT + 7) >> 3
+            grid = 8 * mtb_n * ntx                     # launcher: mtb_n * roundup(NT, 8)
+            assert grid == mtb_n * ((NT + 7) // 8 * 8)
+            seen = {}
+            for b in range(grid):
+                x, q = b & 7, b >> 3
+                j = q // mtb_n
+                mtb, nt = q - j * mtb_n, x * ntx + j
+                if nt >= NT:
+                    continue
+                assert (mtb, nt) not in seen
+                seen[(mtb, nt)] = x
+            assert len(seen) == mtb_n * NT
+            for nt in range(NT):                       # one XCD per B tile
+                assert len({seen[(m, nt)] for m in range(mtb_n)}) == 1
+            xcd_of_tile = [seen[(0, nt)] for nt in range(NT)]
+            assert xcd_of_tile == sorted(xcd_of_tile)  # contiguous ranges, in order
+    for nb in (1, 5, 8, 9, 1000, 6272):               # depthwise / stem: virtual block id
+        per = (nb + 7) >> 3
+        vbs = [((b & 7) * per + (b >> 3)) for b in range(8 * per)]
+        live = [v for v in vbs if v < nb]
+        assert sorted(live) == list(range(nb))
+
