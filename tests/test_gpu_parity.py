@@ -253,6 +253,25 @@ def test_dw_fast_fetch_and_staging(gpu_ctx, pkg, plref):
     assert cnt == 18
 
 
+def test_resnet50_and_mobilenetv2_layer_shapes(gpu_ctx, pkg, plref):
+    """BASELINE configs C4 / C5 as parity cases (lite/tests/benchmark/src/convolution_configs.h:381-466, 839-891), batch 1-2:
+    ResNet50: 7x7 s2 p3 stem, 3x3 s1 / s2 dense (im2col route), 1x1 stride-2 downsample, 1x1 with K = 2048;
+    MobileNetV2: relu6 expansions (wide M), linear bottleneck projections (no activation), relu6 depthwise s1 / s2."""
+    rng = np.random.default_rng(113)
+    capi = pkg.capi
+    R50 = [  # n, cin, h, cout, k, pad, stride, act
+        (1, 3, 224, 64, 7, 3, 2, 1), (2, 64, 56, 64, 3, 1, 1, 1), (1, 128, 56, 128, 3, 1, 2, 1),
+        (1, 256, 56, 512, 1, 0, 2, 0), (2, 2048, 7, 512, 1, 0, 1, 1), (1, 512, 7, 512, 3, 1, 1, 1)]
+    for (n, cin, h, cout, k, pad, st, act) in R50:
+        assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, h, cout, k, k, (pad,) * 4, st, 1, 1, act, 0.0, True, rng) == 1
+    V2 = [(2, 16, 112, 96, 1, 0, 1, 2), (2, 96, 56, 24, 1, 0, 1, 0), (2, 144, 56, 24, 1, 0, 1, 0), (2, 320, 7, 1280, 1, 0, 1, 2),
+          (2, 160, 7, 960, 1, 0, 1, 2)]
+    for (n, cin, h, cout, k, pad, st, act) in V2:
+        assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, h, cout, k, k, (pad,) * 4, st, 1, 1, act, 6.0, True, rng) == 1
+    for (c, h, st) in [(96, 112, 2), (144, 56, 1), (192, 28, 2), (576, 14, 1), (960, 7, 1)]:
+        assert _check_all_kinds(gpu_ctx, capi, plref, 2, c, h, h, c, 3, 3, (1, 1, 1, 1), st, 1, c, 2, 6.0, True, rng, depthwise=True) == 1
+
+
 def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
     capi = pkg.capi
     g = load_golden(golden_files("fc_")[0])
