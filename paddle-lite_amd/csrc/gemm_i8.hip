@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.K); PLHIP_PRELOAD(g.KS); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP);
   PLHIP_PRELOAD(g.NB); PLHIP_PRELOAD(g.x_bstride); PLHIP_PRELOAD(g.y_bstride); PLHIP_PRELOAD(g.MT); PLHIP_PRELOAD(g.NT);
   PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg);
+  PLHIP_PRELOAD(g.im_kw); PLHIP_PRELOAD(g.im_khkw); PLHIP_PRELOAD(g.im_c); PLHIP_PRELOAD(g.im_ph); PLHIP_PRELOAD(g.im_pw); PLHIP_PRELOAD(g.im_oh);
   constexpr int GD_NS = GD_D + 1;
   constexpr int SLOT = AREG ? 4096 : 4096 + 4 * MA * 1024;
   constexpr int PER = 1 + MA;  // vector-memory instructions per wave per K-step (1 B piece + MA A fragments)
@@ -353,7 +354,13 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   skip = skip < 0 ? 0 : skip;
   const bool nvalid = b < g.NB && skip < 4;
   if (!nvalid) { b = 0; j = 0; skip = 0; }
-  const int hw = j < full16 ? j : j + rem16 - 16;
+  int hw = j < full16 ? j : j + rem16 - 16;
+  const bool implicit = g.im_kw > 0;  // wave-uniform
+  if (implicit) {  // "image" = output row (batch image, oh): the epilogue wants the batch image and hw = oh*OW + column
+    const int bi = b / g.im_oh;
+    hw += (b - bi * g.im_oh) * g.HWX;
+    b = bi;
+  }
   // my 16-byte piece of the B tile: row 8*wave + lane/8 of the K-step, columns 16*(lane&7) ...
   const int prow = 8 * wave + (lane >> 3);
   const int8_t* xb;
@@ -362,8 +369,22 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
     int pb = np / HWP;
     int pj = np - pb * HWP;
     if (pb >= g.NB) { pb = 0; pj = 0; }
-    xb = g.x + (size_t)pb * g.x_bstride + (pj < full16 ? pj : g.HWX - 16);
+    const int pcol = pj < full16 ? pj : g.HWX - 16;
+    if (implicit) {
+      const int bi = pb / g.im_oh, oh = pb - bi * g.im_oh;
+      xb = g.x + ((size_t)bi * g.im_c * g.im_ph + oh) * g.im_pw + pcol;
+    } else {
+      xb = g.x + (size_t)pb * g.x_bstride + pcol;
+    }
   }
+  // implicit GEMM: (channel, tap) of this lane's K-row, advanced by 32 rows per issued K-step (issue() is called with
+  // consecutive K-steps), so that no division sits in the loop
+  int kc = 0, krs = 0;
+  if (implicit) {
+    kc = prow / g.im_khkw;
+    krs = prow - kc * g.im_khkw;
+  }
+  const int kc_step = implicit ? 32 / g.im_khkw : 0, krs_step = implicit ? 32 - kc_step * g.im_khkw : 0;
   const int8_t* ab = g.wp + (size_t)mtc * MA * g.KS * 1024 + lane * 16;
   const int KS = g.KS;
   float* lsb = reinterpret_cast<float*>(ring + GD_NS * SLOT) + wave * 2 * MA * 32;
@@ -377,9 +398,24 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
 
   auto issue = [&](int ks, int slot) {
     uint8_t* sb = ring + slot * SLOT;
-    int k = ks * 32 + prow;
-    k = k < g.K ? k : g.K - 1;  // rows past K meet zero-padded weights
-    __builtin_amdgcn_global_load_lds((glb_ptr)(xb + (size_t)k * g.XP), (lds_ptr)(sb + wave * 1024), 16, 0, 0);
+    size_t koff;
+    if (implicit) {
+      // rows past K meet zero-padded weights: any in-bounds address will do (the last real tap)
+      const int c = kc < g.im_c ? kc : g.im_c - 1, rs = kc < g.im_c ? krs : g.im_khkw - 1;
+      const int r = (rs * ((65536 + g.im_kw - 1) / g.im_kw)) >> 16;  // rs / kw, exact for rs < 128, kw <= 11
+      koff = ((size_t)c * g.im_ph + r) * g.im_pw + (rs - r * g.im_kw);
+      kc += kc_step;
+      krs += krs_step;
+      if (krs >= g.im_khkw) {
+        krs -= g.im_khkw;
+        ++kc;
+      }
+    } else {
+      int k = ks * 32 + prow;
+      k = k < g.K ? k : g.K - 1;  // rows past K meet zero-padded weights
+      koff = (size_t)k * g.XP;
+    }
+    __builtin_amdgcn_global_load_lds((glb_ptr)(xb + koff), (lds_ptr)(sb + wave * 1024), 16, 0, 0);
     if (!AREG) {
 #pragma unroll
       for (int a = 0; a < MA; ++a)
@@ -828,7 +864,7 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
   GemmArgs g = g_in;
   const bool mfull = g.M % (32 * MA) == 0;
   const int var = gemm_variant();
-  const bool use_ws = MA == 2 && aligned && var == 5;  // experiment, opt-in: slower than the ring
+  const bool use_ws = MA == 2 && aligned && var == 5 && g.im_kw == 0;  // experiment, opt-in: slower than the ring
   if (use_ws) {
     const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
     if (vec_store && mfull)
@@ -840,7 +876,8 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
     return;
   }
   // (32-row wave tiles with a short K -- e.g. 128->128 at 56x56 -- run faster on the register-staged kernel: 24.8 vs 26.6 us)
-  const bool use_dma = g.HWX >= 16 && g.KS >= 4 && (var == 3 || (var == 0 && g.MT >= 4 && (MA == 2 || g.KS >= 8)));
+  const bool use_dma = g.im_kw > 0 ||  // the implicit-GEMM route exists only in the ring kernel (conv_geom checked the shape)
+                       (g.HWX >= 16 && g.KS >= 4 && (var == 3 || (var == 0 && g.MT >= 4 && (MA == 2 || g.KS >= 8))));
   if (use_dma) {
     g.NT = (int)(((long)g.NB * ((g.HWX + 15) & ~15) + 127) / 128);  // 16-byte padded column space of this kernel
     const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
@@ -918,7 +955,7 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
     dbg_env = e ? atoi(e) : 0;
   }
   g.dbg = dbg_env;
-  if (ma == 2 && ((ma_env == 0 && g.M <= 128 && g.M > 64) || ma_env == 1)) ma = 1;
+  if (ma == 2 && ((ma_env == 0 && g.M <= 128 && g.M > 64) || (ma_env == 1 && g.im_kw == 0))) ma = 1;
   g.MT = (g.M + 32 * ma - 1) / (32 * ma);
   if (ma == 1) {
     if (out == OUT_I32) launch_gemm_t<1, OUT_I32>(g, vec_store, aligned_loads, s);
@@ -935,6 +972,48 @@ void launch_pack_weights(const int8_t* w, int8_t* wp, int G, int Mg, int Kg, int
   const size_t total = (size_t)G * MT32 * KS * 1024;
   const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wp, G, Mg, Kg, MT32, KS);
+}
+
+// Zero-padded copy of the input for the implicit-GEMM route: xp[plane][ph][pw] = x[plane][ph - pt][pw - pl] or 0.
+// One thread = one aligned dword of the flat padded buffer (two divisions, then carry propagation byte by byte).
+__global__ void pad_input_i8_kernel(PadArgs a) {
+  const long nq = a.total >> 2;
+  const int plane_sz = a.ph * a.pw;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    const long o = q << 2;
+    int plane = (int)(o / plane_sz);
+    const int rem = (int)(o - (long)plane * plane_sz);
+    int ph = rem / a.pw, pw = rem - ph * a.pw;
+    uint32_t v = 0;
+    {  // interior dword (the common case): one unaligned 4-byte load
+      const int ih = ph - a.pt, iw = pw - a.pl;
+      if (plane < a.planes && pw + 3 < a.pw && ih >= 0 && ih < a.h && iw >= 0 && iw + 3 < a.w) {
+        __builtin_memcpy(&v, a.x + ((size_t)plane * a.h + ih) * a.w + iw, 4);
+        reinterpret_cast<uint32_t*>(a.xp)[q] = v;
+        continue;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ih = ph - a.pt, iw = pw - a.pl;
+      if (plane < a.planes && ih >= 0 && ih < a.h && iw >= 0 && iw < a.w)
+        v |= (uint32_t)(uint8_t)a.x[((size_t)plane * a.h + ih) * a.w + iw] << (8 * i);
+      if (++pw == a.pw) {
+        pw = 0;
+        if (++ph == a.ph) {
+          ph = 0;
+          ++plane;
+        }
+      }
+    }
+    reinterpret_cast<uint32_t*>(a.xp)[q] = v;
+  }
+}
+
+void launch_pad_input(const PadArgs& a, hipStream_t s) {
+  long blocks = ((a.total >> 2) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(pad_input_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
 void launch_im2col(const Im2colArgs& a, hipStream_t s) {

@@ -44,13 +44,26 @@ plhip_status fail(plhip_ctx* c, plhip_status st, const char* fmt, const char* a 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
-enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2 };
+enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2, IMPL_IMPLICIT_GEMM = 3 };
 
 struct ConvGeom {
   int oh, ow, G, Mg, Cg, Kg, N, Np, MA, MT, MT32, KS;
   bool is_1x1_s1_p0;
   ConvImpl impl;  // a pure function of the descriptor, so that pack and run agree
 };
+
+static bool implicit_gemm_disabled() {  // PLHIP_IMPLICIT_GEMM=0: A/B runs against the im2col route
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PLHIP_IMPLICIT_GEMM");
+    v = (e && atoi(e) == 0) ? 1 : 0;
+  }
+  return v == 1;
+}
+static size_t padded_input_bytes(const plhip_conv_desc* d) {  // + slack: the last 16-byte pieces run past the last row
+  const size_t b = (size_t)d->n * d->cin * (d->h + d->pad[0] + d->pad[1]) * (d->w + d->pad[2] + d->pad[3]);
+  return ((b + 3) & ~(size_t)3) + 64;
+}
 
 bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   if (!d || d->n < 1 || d->cin < 1 || d->cout < 1 || d->h < 1 || d->w < 1 || d->kh < 1 || d->kw < 1) return false;
@@ -85,6 +98,18 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
                                              d->groups, d->pad[2]))
     g->impl = IMPL_DIRECT_3X3S2;
   else g->impl = IMPL_IM2COL_GEMM;
+  // dense k x k stride-1 convs whose GEMM fits the LDS-DMA ring kernel (64-row wave tiles: M > 128, 32-row tiles: 96 < M <=
+  // 128 with K >= 256) skip the im2col buffer: implicit GEMM on a zero-padded copy of the input (1.08x the input
+  // instead of kh*kw x: BASELINE config #2 spent 128 of 149 us writing its 57.8 MB im2col buffer)
+  if (g->impl == IMPL_IM2COL_GEMM && d->groups == 1 && d->stride[0] == 1 && d->stride[1] == 1 && d->dil[0] == 1 &&
+      d->dil[1] == 1 && g->ow >= 16 && d->kw <= 11 && d->kh * d->kw <= 121 && !implicit_gemm_disabled()) {
+    const int ma = (g->MA == 2 && g->Mg <= 128 && g->Mg > 64) ? 1 : g->MA;  // launch_gemm_i8's tile choice
+    const int mt = cdiv(g->Mg, 32 * ma);
+    const size_t padded = (size_t)d->n * d->cin * (d->h + d->pad[0] + d->pad[1]) * (d->w + d->pad[2] + d->pad[3]);
+    if (mt >= 4 && g->KS >= 4 && (ma == 2 || g->KS >= 8) && padded < ((size_t)1 << 31) - 4096 &&
+        (size_t)d->n * g->oh * rup(g->ow, 16) < ((size_t)1 << 31) - 256)
+      g->impl = IMPL_IMPLICIT_GEMM;
+  }
   return true;
 }
 
@@ -228,6 +253,7 @@ plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d, c
 size_t plhip_conv_workspace_bytes(const plhip_conv_desc* d) {
   ConvGeom g;
   if (!conv_geom(d, &g)) return 0;
+  if (g.impl == IMPL_IMPLICIT_GEMM) return padded_input_bytes(d);
   if (g.impl != IMPL_IM2COL_GEMM) return 0;
   return (size_t)d->n * g.G * g.Kg * g.Np;
 }
@@ -238,6 +264,7 @@ const char* plhip_conv_impl_name(const plhip_conv_desc* d) {
   if (g.impl == IMPL_GEMM_1X1) return "conv1x1s1_gemm_int8_mfma32x32x32";
   if (g.impl == IMPL_DIRECT_3X3S2)  // one MFMA K-step when the taps fit (Cin <= 3, OW % 4 == 0), v_dot4 otherwise
     return (d->cin * 3 <= 9 && (g.ow & 3) == 0) ? "conv_3x3s2_direct_int8_mfma32x32x32" : "conv_3x3s2_direct_int8_dot4";
+  if (g.impl == IMPL_IMPLICIT_GEMM) return "conv_implicit_gemm_int8_mfma32x32x32";
   return "conv_im2col_gemm_int8_mfma32x32x32";
 }
 
@@ -267,6 +294,46 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     a.oh = g.oh; a.ow = g.ow; a.pt = d->pad[0]; a.pl = d->pad[2]; a.act = d->act; a.alpha = d->act_alpha;
     plhip::launch_conv3x3s2_direct(a, (int)out, ctx->stream);
     LAUNCHCHK(ctx, "conv3x3s2_direct");
+    return PLHIP_OK;
+  }
+  if (g.impl == IMPL_IMPLICIT_GEMM) {
+    const size_t need = padded_input_bytes(d);
+    if (!workspace || workspace_bytes < need || !aligned(workspace, 4))
+      return fail(ctx, PLHIP_ERR_WORKSPACE, "plhip_conv2d_int8: padded-input workspace missing, too small or unaligned");
+    const int PH = d->h + d->pad[0] + d->pad[1], PW = d->w + d->pad[2] + d->pad[3];
+    plhip::PadArgs pa;
+    pa.x = x;
+    pa.xp = (int8_t*)workspace;
+    pa.planes = d->n * d->cin;
+    pa.h = d->h; pa.w = d->w; pa.ph = PH; pa.pw = PW; pa.pt = d->pad[0]; pa.pl = d->pad[2];
+    pa.total = (long)need;
+    plhip::launch_pad_input(pa, ctx->stream);
+    LAUNCHCHK(ctx, "pad_input");
+    const size_t esz_i = out == PLHIP_OUT_I8 ? 1 : 4;
+    plhip::GemmArgs a;
+    a.wp = (const int8_t*)w_packed;
+    a.x = (const int8_t*)workspace;
+    a.y = y;
+    a.scale = scale;
+    a.bias = bias;
+    a.M = g.Mg;
+    a.K = g.Kg;
+    a.KS = g.KS;
+    a.HWX = g.ow;          // an "image" of the column space is one output row
+    a.HWY = g.N;
+    a.XP = 0;
+    a.x_bytes = (long)need;
+    a.NB = d->n * g.oh;
+    a.x_bstride = 0;
+    a.y_bstride = (size_t)d->cout * g.N;
+    a.MT = g.MT;
+    a.NT = 0;              // set by the launcher from NB and HWX
+    a.act = d->act;
+    a.alpha = d->act_alpha;
+    a.im_kw = d->kw; a.im_khkw = d->kh * d->kw; a.im_c = d->cin; a.im_ph = PH; a.im_pw = PW; a.im_oh = g.oh;
+    const bool vec_store_i = (g.ow & 3) == 0 && aligned(y, 4 * esz_i);
+    plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store_i, true, ctx->stream);
+    LAUNCHCHK(ctx, "gemm_i8_implicit");
     return PLHIP_OK;
   }
   const bool direct = g.impl == IMPL_GEMM_1X1;
@@ -333,6 +400,7 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     a.NT = cdiv(d->n * hwx, 128);
     a.act = d->act;
     a.alpha = d->act_alpha;
+    a.im_kw = a.im_khkw = a.im_c = a.im_ph = a.im_pw = a.im_oh = 0;
     plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store, aligned_loads, ctx->stream);
     LAUNCHCHK(ctx, "gemm_i8");
   }

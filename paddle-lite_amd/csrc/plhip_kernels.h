@@ -22,7 +22,19 @@ struct GemmArgs {
   int act;
   float alpha;
   int dbg;             // PLHIP_GEMM_DEBUG (timing experiments only): 1 = skip the epilogue, 2 = skip the K loop
+  // implicit GEMM (dense kh x kw, stride 1, dilation 1) on a zero-PADDED copy of the input [b][c][PH][PW]: im_kw > 0.
+  // Then an "image" of the column space is one output row (NB = batch * OH, HWX = OW) and K-row k = (c, r, s) of it
+  // starts at  x + ((b*C + c)*PH + oh + r)*PW + s : contiguous bytes, so the B tile still moves as 16-byte pieces.
+  int im_kw, im_khkw, im_c, im_ph, im_pw, im_oh;
 };
+
+struct PadArgs {
+  const int8_t* x;  // [planes][h][w]
+  int8_t* xp;       // [planes][ph][pw] + slack, zero border
+  int planes, h, w, ph, pw, pt, pl;
+  long total;       // bytes of xp to write (multiple of 4: planes*ph*pw rounded up + slack)
+};
+void launch_pad_input(const PadArgs& a, hipStream_t s);
 
 struct Im2colArgs {
   const int8_t* x;

@@ -272,6 +272,23 @@ def test_resnet50_and_mobilenetv2_layer_shapes(gpu_ctx, pkg, plref):
         assert _check_all_kinds(gpu_ctx, capi, plref, 2, c, h, h, c, 3, 3, (1, 1, 1, 1), st, 1, c, 2, 6.0, True, rng, depthwise=True) == 1
 
 
+def test_implicit_gemm_route(gpu_ctx, pkg, plref):
+    """Dense k x k stride-1 convs on the implicit-GEMM route (zero-padded input copy + ring kernel): kernel shapes 3x3,
+    5x5, 1x3, 3x1, 7x7, 2x2; symmetric / asymmetric / zero pads; OW = 16, 17, 20, 30, 56 (end-aligned last piece, skipped
+    duplicate columns); K tails (Cin*kh*kw % 32 != 0); 32- and 64-row wave tiles; batch 1-3; all output kinds."""
+    rng = np.random.default_rng(114)
+    capi = pkg.capi
+    cases = [  # n, cin, h, w, cout, kh, kw, pads(t,b,l,r), act
+        (2, 64, 20, 20, 128, 3, 3, (1, 1, 1, 1), 1), (1, 32, 18, 18, 256, 3, 3, (0, 0, 0, 0), 0), (3, 24, 16, 17, 200, 5, 5, (2, 2, 2, 2), 2),
+        (2, 100, 9, 30, 256, 1, 3, (0, 0, 1, 1), 4), (1, 96, 30, 16, 128, 3, 1, (1, 1, 0, 0), 1), (1, 8, 24, 24, 256, 7, 7, (3, 3, 3, 3), 1),
+        (2, 70, 17, 21, 320, 2, 2, (1, 0, 0, 1), 0), (1, 64, 56, 56, 128, 3, 3, (1, 1, 1, 1), 1), (2, 33, 12, 40, 512, 3, 3, (2, 1, 0, 2), 2)]
+    for (n, cin, h, w, cout, kh, kw, pads, act) in cases:
+        d = capi.conv_desc(n, cin, h, w, cout, kh, kw, pads, (1, 1), (1, 1), 1, act, 0.0)
+        assert gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) == b"conv_implicit_gemm_int8_mfma32x32x32", (cin, cout, kh, kw)
+        assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, kh, kw, pads, 1, 1, 1, act, 6.0 if act == 2 else 0.25,
+                                act != 4, rng) == 1
+
+
 def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
     capi = pkg.capi
     g = load_golden(golden_files("fc_")[0])
