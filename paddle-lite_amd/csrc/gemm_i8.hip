@@ -980,10 +980,10 @@ __global__ void pad_input_i8_kernel(PadArgs a) {
   const long nq = a.total >> 2;
   const int plane_sz = a.ph * a.pw;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
-    const long o = q << 2;
-    int plane = (int)(o / plane_sz);
-    const int rem = (int)(o - (long)plane * plane_sz);
-    int ph = rem / a.pw, pw = rem - ph * a.pw;
+    const uint32_t o = (uint32_t)q << 2;  // the padded buffer is < 2^31 bytes (conv_geom): 32-bit divisions
+    int plane = (int)(o / (uint32_t)plane_sz);
+    const int rem = (int)(o - (uint32_t)plane * (uint32_t)plane_sz);
+    int ph = (int)((uint32_t)rem / (uint32_t)a.pw), pw = rem - ph * a.pw;
     uint32_t v = 0;
     {  // interior dword (the common case): one unaligned 4-byte load
       const int ih = ph - a.pt, iw = pw - a.pl;
