@@ -279,12 +279,14 @@ __device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, 
     sidx = (int)(strip & (spp - 1));
     plane = strip >> a.spp_log2;
     ch = (int)(plane & (a.C - 1));
-  } else {
-    xq = (int)(gid % owq);
-    const long strip = gid / owq;
-    sidx = (int)(strip % spp);
-    plane = strip / spp;
-    ch = (int)(plane % a.C);
+  } else {  // magic-number divisions (total_lanes < 2^31, checked by the launcher): no hardware divide sequences
+    const uint32_t g32 = (uint32_t)gid;
+    const uint32_t strip = fastdiv_u31(g32, a.div_owq_m, a.div_owq_s);
+    xq = (int)(g32 - strip * (uint32_t)owq);
+    const uint32_t pl32 = fastdiv_u31(strip, a.div_spp_m, a.div_spp_s);
+    sidx = (int)(strip - pl32 * (uint32_t)spp);
+    plane = (long)pl32;
+    ch = (int)(pl32 - fastdiv_u31(pl32, a.div_c_m, a.div_c_s) * (uint32_t)a.C);
   }
   const int oy0 = sidx * RS;
   const int iy0 = oy0 * S - a.pt;
@@ -471,12 +473,14 @@ __device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, ui
     sidx = (int)(strip & (spp - 1));
     plane = strip >> a.spp_log2;
     ch = (int)(plane & (a.C - 1));
-  } else {
-    xq = (int)(gid % owq);
-    const long strip = gid / owq;
-    sidx = (int)(strip % spp);
-    plane = strip / spp;
-    ch = (int)(plane % a.C);
+  } else {  // magic-number divisions (total_lanes < 2^31, checked by the launcher): no hardware divide sequences
+    const uint32_t g32 = (uint32_t)gid;
+    const uint32_t strip = fastdiv_u31(g32, a.div_owq_m, a.div_owq_s);
+    xq = (int)(g32 - strip * (uint32_t)owq);
+    const uint32_t pl32 = fastdiv_u31(strip, a.div_spp_m, a.div_spp_s);
+    sidx = (int)(strip - pl32 * (uint32_t)spp);
+    plane = (long)pl32;
+    ch = (int)(pl32 - fastdiv_u31(pl32, a.div_c_m, a.div_c_s) * (uint32_t)a.C);
   }
   const int oy0 = sidx * RS;
   const int iy0 = oy0 * S - a.pt;
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
   PLHIP_PRELOAD(a.planes); PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.h); PLHIP_PRELOAD(a.w); PLHIP_PRELOAD(a.oh); PLHIP_PRELOAD(a.ow);
   PLHIP_PRELOAD(a.pt); PLHIP_PRELOAD(a.pl); PLHIP_PRELOAD(a.total_lanes); PLHIP_PRELOAD(a.owq_log2); PLHIP_PRELOAD(a.spp_log2);
   PLHIP_PRELOAD(a.fast_div); PLHIP_PRELOAD(a.stage_bytes); PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha);
+  PLHIP_PRELOAD(a.div_owq_m); PLHIP_PRELOAD(a.div_spp_m); PLHIP_PRELOAD(a.div_c_m); PLHIP_PRELOAD(a.div_owq_s); PLHIP_PRELOAD(a.div_spp_s); PLHIP_PRELOAD(a.div_c_s);
   extern __shared__ __attribute__((aligned(16))) uint8_t dw_stage[];  // STAGE: 4 waves x stage_bytes
   // XCD-contiguous work: workgroups are dealt round-robin over the 8 XCDs (private L2 each); giving XCD x the x-th eighth
   // of the lane space keeps neighbouring strips (which share their 2 halo rows and the cache lines at their edges) on
@@ -543,6 +548,17 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
   a.owq_log2 = lg2(owq);
   a.spp_log2 = lg2(spp);
   a.fast_div = a.owq_log2 >= 0 && a.spp_log2 >= 0 && lg2(a.C) >= 0;
+  auto magic = [&](long d, unsigned& m, int& sh) {
+    const int l = lg2(d);
+    if (l >= 0) { m = 0; sh = l; return; }
+    int sc = 0;
+    while ((1L << sc) < d) ++sc;  // ceil(log2 d)
+    m = (unsigned)(((1ULL << (31 + sc)) / (unsigned long long)d) + 1ULL);
+    sh = sc - 1;
+  };
+  magic(owq, a.div_owq_m, a.div_owq_s);
+  magic(spp, a.div_spp_m, a.div_spp_s);
+  magic(a.C, a.div_c_m, a.div_c_s);
   // output staging through LDS: int8 output, narrow planes, a wave = whole strips, strips = whole rows of the plane
   static int stage_env = -1;
   if (stage_env < 0) {

@@ -5,6 +5,11 @@
 
 namespace plhip {
 
+// n / d for n < 2^31 with the host-prepared (magic, shift) pair of DwArgs (magic == 0: d is a power of two)
+__device__ __forceinline__ uint32_t fastdiv_u31(uint32_t n, uint32_t magic, int sh) {
+  return magic ? (__umulhi(n, magic) >> sh) : (n >> sh);
+}
+
 template <int ACT>
 __device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, float b2, float alpha, float lo2, float hi2) {
   if (ACT == ACT_RELU || ACT == ACT_RELU6) {

@@ -58,6 +58,10 @@ struct DwArgs {
   int pitch;    // LDS row pitch in bytes (multiple of 4)
   long total_lanes;               // direct kernel: planes * strips * quads
   int owq_log2, spp_log2, fast_div;  // direct kernel: power-of-two index split
+  // exact division of a 31-bit index by a run-time constant without a divide: q = d is a power of two ? n >> sh
+  // : mulhi(n, magic) >> sh  (magic = floor(2^(31+s)/d) + 1, s = ceil(log2 d), sh = s - 1; exact for n < 2^31)
+  unsigned div_owq_m, div_spp_m, div_c_m;
+  int div_owq_s, div_spp_s, div_c_s;
   int stage_bytes;                // direct kernel: LDS bytes per wave for output staging (0 = off)
   int act;
   float alpha;

@@ -102,3 +102,21 @@ def test_xcd_contiguous_maps_cover_every_tile_once():
         live = [v for v in vbs if v < nb]
         assert sorted(live) == list(range(nb))
 
+
+def test_magic_division_is_exact_below_2_31():
+    """Host mirror of fastdiv_u31 (csrc/dw_common.h) and of the (magic, shift) pairs launch_dw_direct_s prepares:
+    q = mulhi(n, floor(2^(31+s)/d) + 1) >> (s-1), s = ceil(log2 d), must equal n // d for every n < 2^31."""
+    rng = np.random.default_rng(5)
+    for d in list(range(1, 130)) + [196, 255, 257, 1000, 1023, 1025, 4097, 65535, 65537, 1 << 20, (1 << 20) + 1, (1 << 30) - 1]:
+        if d & (d - 1) == 0:
+            magic, sh = 0, d.bit_length() - 1
+        else:
+            sc = (d - 1).bit_length()
+            magic, sh = ((1 << (31 + sc)) // d) + 1, sc - 1
+            assert magic < (1 << 32)
+        ns = np.concatenate([np.arange(0, 4 * d + 2), (np.arange(1, 200) * d) - 1, np.arange(1, 200) * d,
+                             rng.integers(0, 1 << 31, 2000), np.array([(1 << 31) - 1, (1 << 31) - d, ((1 << 31) - 1) // d * d])])
+        ns = ns[(ns >= 0) & (ns < (1 << 31))].astype(np.uint64)
+        q = (ns >> np.uint64(sh)) if magic == 0 else (((ns * np.uint64(magic)) >> np.uint64(32)) >> np.uint64(sh))
+        assert np.array_equal(q, ns // np.uint64(d)), d
+
