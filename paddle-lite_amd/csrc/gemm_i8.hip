@@ -813,35 +813,42 @@ __global__ void pack_weights_kernel(const int8_t* __restrict__ w, int8_t* __rest
 
 // ---- im2col: x NCHW -> col[b][g][Kg][Np], Np = roundup(oh*ow, 4), pad columns and OOB taps = 0 ----
 // Row index k = c*kh*kw + r*kw + q (conv_impl.cc:103-153).  One thread writes one dword (4 columns).
-__global__ void im2col_i8_kernel(Im2colArgs a) {
+// grid = (column-quad tiles, Kg, batch*groups): the row (image, group, channel, tap) is block-uniform, so its decode runs
+// on the scalar unit; a thread does ONE 32-bit division (its first column -> (oy, ox)) and walks the other three columns
+// with a carry.  Stride-1 quads that stay inside one input row are fetched as one unaligned dword.  (The former
+// 1-D form decoded everything per thread with 64-bit divisions: 128 us for the 57.8 MB buffer of BASELINE config #2.)
+__global__ __launch_bounds__(256) void im2col_i8_kernel(Im2colArgs a) {
   const int np4 = a.Np >> 2;
-  const size_t total = (size_t)a.rows * np4;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int q4 = (int)(idx % np4);
-    const size_t row = idx / np4;  // (b*G + g)*Kg + k
-    const int k = (int)(row % a.Kg);
-    const size_t bg = row / a.Kg;
-    const int grp = (int)(bg % a.G);
-    const int b = (int)(bg / a.G);
-    const int kq = k % a.kw;
-    const int kr = (k / a.kw) % a.kh;
-    const int ci = k / (a.kw * a.kh);
-    const int8_t* xp = a.x + ((size_t)b * a.cin + (size_t)grp * a.cin_g + ci) * a.h * a.w;
-    uint32_t out = 0;
+  const int q4 = blockIdx.x * 256 + threadIdx.x;
+  if (q4 >= np4) return;
+  const int k = blockIdx.y;
+  const int bg = blockIdx.z;
+  const int b = bg / a.G, grp = bg - b * a.G;
+  const int khkw = a.kh * a.kw;
+  const int ci = k / khkw, rs = k - ci * khkw;
+  const int kr = rs / a.kw, kq = rs - kr * a.kw;
+  const int8_t* xp = a.x + ((size_t)b * a.cin + (size_t)grp * a.cin_g + ci) * a.h * a.w;
+  const size_t row = (size_t)bg * a.Kg + k;
+  int n = q4 * 4;
+  int oy = (int)((uint32_t)n / (uint32_t)a.ow), ox = n - oy * a.ow;
+  uint32_t out = 0;
+  const int ih0 = oy * a.sh - a.pt + kr * a.dh, iw0 = ox * a.sw - a.pl + kq * a.dw;
+  if (a.sw == 1 && n + 3 < a.N && ox + 3 < a.ow && ih0 >= 0 && ih0 < a.h && iw0 >= 0 && iw0 + 3 < a.w) {
+    __builtin_memcpy(&out, xp + (size_t)ih0 * a.w + iw0, 4);
+  } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int n = q4 * 4 + i;
-      int v = 0;
-      if (n < a.N) {
-        const int oy = n / a.ow, ox = n - oy * a.ow;
-        const int ih = oy * a.sh - a.pt + kr * a.dh;
-        const int iw = ox * a.sw - a.pl + kq * a.dw;
-        if (ih >= 0 && ih < a.h && iw >= 0 && iw < a.w) v = (uint8_t)xp[(size_t)ih * a.w + iw];
+      if (n + i < a.N) {
+        const int ih = oy * a.sh - a.pt + kr * a.dh, iw = ox * a.sw - a.pl + kq * a.dw;
+        if (ih >= 0 && ih < a.h && iw >= 0 && iw < a.w) out |= (uint32_t)(uint8_t)xp[(size_t)ih * a.w + iw] << (8 * i);
       }
-      out |= (uint32_t)v << (8 * i);
+      if (++ox == a.ow) {
+        ox = 0;
+        ++oy;
+      }
     }
-    *reinterpret_cast<uint32_t*>(a.col + row * a.Np + (size_t)q4 * 4) = out;
   }
+  *reinterpret_cast<uint32_t*>(a.col + row * a.Np + (size_t)q4 * 4) = out;
 }
 
 // ---- host-side launchers (called from plhip_capi.hip) ----
@@ -1017,10 +1024,9 @@ void launch_pad_input(const PadArgs& a, hipStream_t s) {
 }
 
 void launch_im2col(const Im2colArgs& a, hipStream_t s) {
-  const size_t total = (size_t)a.rows * (a.Np >> 2);
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(im2col_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  // rows = batch * G * Kg; Kg and batch*G ride on grid.y / grid.z (<= 65535 each, checked by the caller)
+  const unsigned bg = (unsigned)(a.rows / (size_t)a.Kg);
+  hipLaunchKernelGGL(im2col_i8_kernel, dim3((unsigned)(((a.Np >> 2) + 255) / 256), (unsigned)a.Kg, bg), dim3(256), 0, s, a);
 }
 
 }  // namespace plhip

@@ -368,6 +368,8 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     ia.N = g.N;
     ia.Np = g.Np;
     ia.rows = (size_t)d->n * g.G * g.Kg;
+    if (g.Kg > 65535 || (size_t)d->n * g.G > 65535)
+      return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_int8: im2col route needs Kg and batch*groups <= 65535");
     plhip::launch_im2col(ia, ctx->stream);
     LAUNCHCHK(ctx, "im2col");
     bmat = (const int8_t*)workspace;
