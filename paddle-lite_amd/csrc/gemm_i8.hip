@@ -81,10 +81,10 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler too
-  const long wid = (long)blockIdx.x * 4 + wave;
-  if (wid >= (long)g.MT * g.NT) return;  // wave-uniform; the kernel uses no barrier
-  const int mt = (int)(wid % g.MT);
-  const int nt = (int)(wid / g.MT);
+  const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;  // MT * NT < 2^31 (launcher)
+  if (wid >= (uint32_t)g.MT * (uint32_t)g.NT) return;  // wave-uniform; the kernel uses no barrier
+  const int nt = (int)(wid / (uint32_t)g.MT);
+  const int mt = (int)(wid - (uint32_t)nt * (uint32_t)g.MT);
   __shared__ __attribute__((aligned(16))) float lsb_all[4][2 * MA * 32];
   float* lsb = lsb_all[wave];
   const int c = lane & 31, h = lane >> 5;
@@ -98,14 +98,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   const int8_t* xb = g.x + (size_t)b * g.x_bstride + hw;
   const long room = g.x_bytes - ((long)b * (long)g.x_bstride + hw);  // bytes from xb to the end of the tensor
 
-  v16i acc[MA][4];
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][i][r] = 0;
-
+  v16i acc[MA][4];  // first written by K-step 0 (zero addend): no separate zeroing of the 64*MA registers
   uint32_t raw[16];
   v4i af[MA];
   load_b<ALIGNED>(xb, 0, h, g.K, g.XP, room, raw);
@@ -113,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
   float my_s = 1.f, my_b = 0.f;  // this lane's share of the tile's scale / bias, issued behind the first operand loads
   if (OUT != OUT_I32) load_scale_bias<MA>(g, mt, lane, my_s, my_b);
 
-  for (int ks = 0; ks < ((g.dbg & 2) ? 0 : g.KS); ++ks) {
+  auto kbody = [&](int ks, auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;
     v4i bf[4];
 #pragma unroll
     for (int jg = 0; jg < 4; ++jg) {
@@ -131,12 +125,15 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_nchw_kernel(GemmArgs g) {
       load_b<ALIGNED>(xb, ks + 1, h, g.K, g.XP, room, raw);
       load_a<MA>(g.wp, mt, g.KS, ks + 1, lane, af);
     }
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int a = 0; a < MA; ++a)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[a], bf[i], acc[a][i], 0, 0, 0);
-  }
+        acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[a], bf[i], FIRST ? zero : acc[a][i], 0, 0, 0);
+  };
+  kbody(0, std::integral_constant<bool, true>{});  // (PLHIP_GEMM_DEBUG bit 1 cannot skip the first step any more)
+  for (int ks = 1; ks < ((g.dbg & 2) ? 0 : g.KS); ++ks) kbody(ks, std::integral_constant<bool, false>{});
 
   if (OUT != OUT_I32) store_scale_bias<MA, OUT>(lsb, lane, my_s, my_b);
   if (!nvalid || (g.dbg & 1)) return;
@@ -193,13 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
   const int8_t* xb = g.x + (size_t)b * g.x_bstride + hw;
   const long room = g.x_bytes - ((long)b * (long)g.x_bstride + hw);
 
-  v16i acc[MA][4];
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][i][r] = 0;
+  v16i acc[MA][4];  // first written by K-step 0 (zero addend)
 
   const int KS = g.KS;
   const int S = (KS + 3) >> 2;
@@ -220,15 +211,19 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) bs[buf][wave][i][lane] = bf[i];
   };
-  auto kstep = [&](int buf, int kk, const v4i (&af)[MA]) {
+  auto kstep_t = [&](int buf, int kk, const v4i (&af)[MA], auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     v4i bf[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bf[i] = bs[buf][kk][i][lane];
 #pragma unroll
     for (int a = 0; a < MA; ++a)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[a], bf[i], acc[a][i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[a], bf[i], FIRST ? zero : acc[a][i], 0, 0, 0);
   };
+  auto kstep = [&](int buf, int kk, const v4i (&af)[MA]) { kstep_t(buf, kk, af, std::integral_constant<bool, false>{}); };
   auto load_a_c = [&](int ks, v4i (&af)[MA]) {  // clamped: K-steps past the end reload the last one (never used)
     load_a<MA>(g.wp, mtc, KS, ks < KS ? ks : KS - 1, lane, af);
   };
@@ -250,7 +245,10 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
     if (more && myks < KS) load_b<ALIGNED>(xb, myks, h, g.K, g.XP, room, raw);
     // 4 K-steps, A ring: slot kk holds K-step ks0+kk; refill two steps ahead
     load_a_c(ks0 + 2, a2);
-    if (mactive) kstep(buf, 0, a0);
+    if (mactive) {
+      if (s == 0) kstep_t(buf, 0, a0, std::integral_constant<bool, true>{});  // uniform
+      else kstep(buf, 0, a0);
+    }
     load_a_c(ks0 + 3, a3);
     if (mactive && ks0 + 1 < KS) kstep(buf, 1, a1);
     load_a_c(ks0 + 4, a0);
@@ -460,12 +458,14 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   if (OUT != OUT_I32) load_scale_bias<MA>(g, mtc, lane, my_s, my_b);  // 2 more vmcnt entries, younger than the prologue DMA
   __builtin_amdgcn_sched_barrier(0);
   v16i acc[MA][4];
+  if (!AREG) {  // AREG: straight-line K loop, K-step 0 multiplies into a zero addend instead (no 64*MA v_mov)
 #pragma unroll
-  for (int a = 0; a < MA; ++a)
+    for (int a = 0; a < MA; ++a)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][i][r] = 0;
+        for (int r = 0; r < 16; ++r) acc[a][i][r] = 0;
+  }
 
   auto read_slot = [&](int slot, uint32_t (&raw)[16], v4i (&af)[MA]) {
     const uint8_t* sb = ring + slot * SLOT;
@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   // one iteration; YOUNGER = my K-steps issued after ks+1 that may still be in flight at the wait, ISSUE / NEXT: whether
   // K-step ks+AHEAD / ks+1 exists (compile-time in the steady state and in the peeled tail)
   int rslot = 1, islot = AHEAD % GD_NS;
-  auto step = [&](int ks, auto younger_c, auto issue_c, auto next_c, auto ring_c) {
+  const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto step = [&](int ks, auto younger_c, auto issue_c, auto next_c, auto ring_c, auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;  // K-step 0 of the straight-line (AREG) loop
     constexpr int RI = AREG ? decltype(ring_c)::value : 0;  // AREG: K-step ks lives in aring[ks % 4]
     constexpr int YOUNGER = decltype(younger_c)::value;
     constexpr bool ISSUE = decltype(issue_c)::value;
@@ -527,7 +529,8 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
     for (int a = 0; a < MA; ++a)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AREG ? aring[RI][a] : af_cur[a], bf_cur[i], acc[a][i], 0, 0, 0);
+        acc[a][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AREG ? aring[RI][a] : af_cur[a], bf_cur[i],
+                                                          (AREG && FIRST) ? zero16 : acc[a][i], 0, 0, 0);
     if (NEXT) transpose(raw, bf_nxt);
     // schedule: [MFMA + one DMA piece] x (pieces issued here), bare MFMAs, then the remaining MFMAs share the transposes
     constexpr int NM = 4 * MA;
@@ -564,33 +567,42 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
     // unrolled by the ring size: K-step ks uses aring[ks % 4]; KS == 4 * NG, so the last group is the peeled tail
     if (!(g.dbg & 2)) {
       int ks = 0;
-#pragma unroll
-      for (int gi = 0; gi + 1 < NG; ++gi, ks += 4) {
-        step(ks, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 0>{});
-        step(ks + 1, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 1>{});
-        step(ks + 2, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 2>{});
-        step(ks + 3, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 3>{});
+      // (the very first step multiplies into a zero addend: FIRST)
+      if (NG > 1) {
+        step(0, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 0>{}, T_{});
+        step(1, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 1>{}, F_{});
+        step(2, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 2>{}, F_{});
+        step(3, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 3>{}, F_{});
+        ks = 4;
       }
-      step(ks, integral_constant<int, 2>{}, F_{}, T_{}, integral_constant<int, 0>{});
-      step(ks + 1, integral_constant<int, 1>{}, F_{}, T_{}, integral_constant<int, 1>{});
-      step(ks + 2, integral_constant<int, 0>{}, F_{}, T_{}, integral_constant<int, 2>{});
-      step(ks + 3, integral_constant<int, 0>{}, F_{}, F_{}, integral_constant<int, 3>{});
+#pragma unroll
+      for (int gi = 1; gi + 1 < NG; ++gi, ks += 4) {
+        step(ks, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 0>{}, F_{});
+        step(ks + 1, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 1>{}, F_{});
+        step(ks + 2, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 2>{}, F_{});
+        step(ks + 3, integral_constant<int, 2>{}, T_{}, T_{}, integral_constant<int, 3>{}, F_{});
+      }
+      if (NG > 1) step(ks, integral_constant<int, 2>{}, F_{}, T_{}, integral_constant<int, 0>{}, F_{});
+      else step(ks, integral_constant<int, 2>{}, F_{}, T_{}, integral_constant<int, 0>{}, T_{});
+      step(ks + 1, integral_constant<int, 1>{}, F_{}, T_{}, integral_constant<int, 1>{}, F_{});
+      step(ks + 2, integral_constant<int, 0>{}, F_{}, T_{}, integral_constant<int, 2>{}, F_{});
+      step(ks + 3, integral_constant<int, 0>{}, F_{}, F_{}, integral_constant<int, 3>{}, F_{});
     }
   } else {
     const int kmain = (g.dbg & 2) ? 0 : KS - AHEAD;
-    for (int ks = 0; ks < kmain; ++ks) step(ks, integral_constant<int, AHEAD - 2>{}, T_{}, T_{}, integral_constant<int, 0>{});
+    for (int ks = 0; ks < kmain; ++ks) step(ks, integral_constant<int, AHEAD - 2>{}, T_{}, T_{}, integral_constant<int, 0>{}, F_{});
     if (!(g.dbg & 2)) {
       // peeled tail: K-steps KS-AHEAD .. KS-1, nothing left to issue, the in-flight count shrinks
       static_assert(AHEAD >= 2 && AHEAD <= 8, "tail is written for 2..8 K-steps ahead");
       int ks = KS - AHEAD;
 #define PLHIP_TAIL(T)                                                                                                    \
   if (AHEAD - 1 > T) {                                                                                                   \
-    step(ks, integral_constant<int, (AHEAD - 2 - T > 0 ? AHEAD - 2 - T : 0)>{}, F_{}, T_{}, integral_constant<int, 0>{}); \
+    step(ks, integral_constant<int, (AHEAD - 2 - T > 0 ? AHEAD - 2 - T : 0)>{}, F_{}, T_{}, integral_constant<int, 0>{}, F_{}); \
     ++ks;                                                                                                                \
   }
       PLHIP_TAIL(0) PLHIP_TAIL(1) PLHIP_TAIL(2) PLHIP_TAIL(3) PLHIP_TAIL(4) PLHIP_TAIL(5) PLHIP_TAIL(6)
 #undef PLHIP_TAIL
-      step(ks, integral_constant<int, 0>{}, F_{}, F_{}, integral_constant<int, 0>{});
+      step(ks, integral_constant<int, 0>{}, F_{}, F_{}, integral_constant<int, 0>{}, F_{});
     }
   }
 
