@@ -12,16 +12,21 @@
 //
 // MI355X design
 //   * one wave owns a (32*MA) x 128 output tile: MA A-fragments x 4 B-fragments of the 32x32x32 MFMA,
-//     accumulators live in 64*MA VGPR/AGPRs;
+//     accumulators live in 64*MA VGPRs (VGPR form: the epilogue reads every value);
 //   * A (weights) is pre-packed once into MFMA fragment order, so a wave's A fragment is one fully
 //     coalesced 1 KiB dwordx4 load served by L2;
-//   * B (activations, K x N with N contiguous = NCHW slab) is loaded with coalesced dword loads
-//     (32 lanes x 4 B = one 128-B line per k row) and transposed IN REGISTERS with v_perm_b32 into the
+//   * B (activations, K x N with N contiguous = NCHW slab) is transposed IN REGISTERS with v_perm_b32 into the
 //     K-contiguous 16-byte-per-lane operand the MFMA wants: lane (c = lane&31, h = lane>>5) ends up
 //     with, for i = 0..3, column n = 4c+i, k = 16h..16h+15.  MFMA i therefore computes columns
 //     {4c+i}, so each lane finishes with 4 CONSECUTIVE n for every output row and the int8 result is
 //     stored as one dword per row (32 lanes x 4 B = 128 contiguous bytes of an NCHW row);
-//   * no LDS and no barrier in this first version: tiles are private to the wave.
+//   * four kernels share this scheme and differ in how B reaches the registers:
+//       gemm_i8_nchw_kernel  private tiles, no LDS, no barrier (M <= 64 or one K-step: purely streaming layers);
+//       gemm_i8_lds_kernel   4 waves split M and share B through LDS in fragment order (register-staged loads);
+//       gemm_i8_dma_kernel   LDS-DMA ring (16-byte pieces, counted vmcnt, one barrier per K-step), A through LDS or
+//                            (NG > 0) straight into a register ring; also the implicit-GEMM route of dense k x k convs;
+//       gemm_i8_ws_kernel    wave-specialised experiment (opt-in).
+//     All of them map block b to the (b % 8)-th eighth of the N tiles (XCD-contiguous work, xcd_tile_map).
 // The MFMA's k-slot <-> (lane>>5, byte) map never matters: A and B use the same one.
 #include <stdlib.h>
 
@@ -169,9 +174,6 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_lds_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mtb_n = (g.MT + 3) >> 2;  // blocks along M
-  // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the mtb_n blocks that
-  // share one B tile get ids that are equal mod 8 (same XCD, adjacent in dispatch order): the tile crosses the fabric
-  // once instead of mtb_n times (PMC: FETCH_SIZE was 3.4x the algorithmic bytes on the M = 512 layers).
   int mtb, nt;
   xcd_tile_map(blockIdx.x, mtb_n, g.NT, mtb, nt);
   if (nt >= g.NT) return;  // block-uniform (grid is padded to 8 N-tiles)
@@ -327,9 +329,6 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mtb_n = (g.MT + 3) >> 2;
-  // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the mtb_n blocks that
-  // share one B tile get ids that are equal mod 8 (same XCD, adjacent in dispatch order): the tile crosses the fabric
-  // once instead of mtb_n times (PMC: FETCH_SIZE was 3.4x the algorithmic bytes on the M = 512 layers).
   int mtb, nt;
   xcd_tile_map(blockIdx.x, mtb_n, g.NT, mtb, nt);
   if (nt >= g.NT) return;  // block-uniform (grid is padded to 8 N-tiles)
