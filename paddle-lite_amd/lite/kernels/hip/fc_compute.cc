@@ -89,7 +89,8 @@ class FcCompute : public KernelLite<TARGET(kHIP), Ptype> {
     HIP_CALL(ctx.ctx(), plhip_fc_int8(ctx.ctx(), m_, k_, n_, param.input->template data<int8_t>(), weights_.raw_data(),
                                       scale_.data<float>(), has_bias_ ? bias_.data<float>() : nullptr, relu_ ? 1 : 0, y, kind));
   }
-  std::string kernel_func_name() const override { return "fc_int8_dot4_hip"; }
+  // the library picks the MFMA kernel when k % 32 == 0 (csrc/misc_ops.hip launch_fc), the dot4 kernels otherwise
+  std::string kernel_func_name() const override { return (k_ % 32 == 0) ? "fc_int8_mfma32x32x32_hip" : "fc_int8_dot4_hip"; }
 
  private:
   DDim last_shape_;
