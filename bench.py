@@ -36,8 +36,8 @@ MFMA_I8_PEAK_TOPS = 256 * 4 * 2048 * 2.4e9 / 1e12
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)   # ~0.13 s timed at 0.42 ms / step: steadier than a 20 ms window
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE config: batch=128 on 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
