@@ -154,3 +154,69 @@ def test_mobilenet_v1_int8_program_vs_oracle_graph(lite, wl, plref):
         assert np.array_equal(p.get_var("dw14", np.int8), ref["dw14"])
     finally:
         p.close()
+
+
+@pytest.mark.gpu
+def test_concurrent_predictors_reproduce_the_serial_result(lite, wl, plref):
+    """bench.py's default mode: several predictors (one host thread + HIP stream each) run whole batches concurrently.
+    Kernels of different predictors then share CUs, LDS and the memory pipes; every run of every predictor must still
+    give exactly the bytes a lone predictor gives (int8 activations and fp32 probabilities compared bit for bit).
+    Batch 32 puts the 14x14 / 7x7 layers on the same kernels as the benchmark (ring GEMM, staged depthwise)."""
+    import threading
+    import torch
+    B, P, ITERS = 32, 3, 25
+    W = wl.make_mobilenet_v1_weights(seed=4321)
+    img = np.random.default_rng(202).uniform(-1, 1, (B, 3, 224, 224)).astype(np.float32)
+    names = ["conv1", "pw4", "dw8", "pw8", "dw14"]
+    ref = {}
+    p0 = lite.Predictor(0)
+    try:
+        out = wl.build_mobilenet_v1(p0, W, B)
+        p0.set_input("image", img)
+        p0.run()
+        p0.sync()
+        for n in names:
+            ref[n] = p0.get_var(n, np.int8)
+        ref[out] = p0.get_var(out, np.float32)
+    finally:
+        p0.close()
+    errs, streams = [], [torch.cuda.Stream(torch.device("cuda", 0)) for _ in range(P)]
+    start = threading.Barrier(P)
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            p = lite.Predictor(0, stream=streams[i].cuda_stream)
+            try:
+                o = wl.build_mobilenet_v1(p, W, B)
+                p.set_input("image", img)
+                p.run()
+                p.sync()
+                start.wait()
+                for it in range(ITERS):
+                    for _ in range(3):  # a few back-to-back steps keep all three streams busy between the checks
+                        p.run(skip_io_copy=True)
+                    p.sync()
+                    for n in names:
+                        if not np.array_equal(p.get_var(n, np.int8), ref[n]):
+                            errs.append("predictor %d iteration %d: %s differs" % (i, it, n))
+                    if not np.array_equal(p.get_var(o, np.float32), ref[out]):
+                        errs.append("predictor %d iteration %d: probabilities differ" % (i, it))
+                    if errs:
+                        return
+            finally:
+                p.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append("predictor %d: %r" % (i, e))
+            try:
+                start.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(P)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs[:5]
+
