@@ -163,7 +163,6 @@ def test_concurrent_predictors_reproduce_the_serial_result(lite, wl, plref):
     give exactly the bytes a lone predictor gives (int8 activations and fp32 probabilities compared bit for bit).
     Batch 32 puts the 14x14 / 7x7 layers on the same kernels as the benchmark (ring GEMM, staged depthwise)."""
     import threading
-    import torch
     B, P, ITERS = 32, 3, 25
     W = wl.make_mobilenet_v1_weights(seed=4321)
     img = np.random.default_rng(202).uniform(-1, 1, (B, 3, 224, 224)).astype(np.float32)
@@ -180,13 +179,12 @@ def test_concurrent_predictors_reproduce_the_serial_result(lite, wl, plref):
         ref[out] = p0.get_var(out, np.float32)
     finally:
         p0.close()
-    errs, streams = [], [torch.cuda.Stream(torch.device("cuda", 0)) for _ in range(P)]
+    errs = []
     start = threading.Barrier(P)
 
     def worker(i):
         try:
-            torch.cuda.set_device(0)
-            p = lite.Predictor(0, stream=streams[i].cuda_stream)
+            p = lite.Predictor(0)  # the HIP context and its stream are per host thread (TargetWrapperHip)
             try:
                 o = wl.build_mobilenet_v1(p, W, B)
                 p.set_input("image", img)
