@@ -160,6 +160,7 @@ def main():
     gather = (sharding.PipelinedGather(torch.empty((args.batch, wl.NUM_CLASSES), dtype=torch.float32, device=dev), dist, world)
               if world > 1 else None)
     loc_ptr = [0]  # device address of the current step's staging buffer (written by run_steps, read by the workers)
+    loc_ready = [None]  # event on the main stream: the collective that last read that buffer has been waited for
 
     class Worker(threading.Thread):
         """One predictor, one host thread, one HIP stream (TargetWrapperHip state is per thread)."""
@@ -194,6 +195,7 @@ def main():
                         preds[self.i].run(skip_io_copy=True)
                         if world > 1:  # stage this shard's probabilities for the all_gather of step s_
                             self.go.acquire()  # the main thread has picked this step's staging buffer
+                            streams[self.i].wait_event(loc_ready[0])  # ... and its previous collective is done
                             preds[self.i].copy_var_to_device("prob", loc_ptr[0] + self.i * p_bytes, p_bytes)
                             self.events[s_].record(streams[self.i])
                             self.step_done.release()
@@ -234,7 +236,9 @@ def main():
                         self.pred.run(skip_io_copy=True)
                         if world > 1:
                             # stage this step's probabilities into the buffer the coordinator picked for step s_
-                            self.pred.copy_var_to_device("prob", self.ptrq.get(), p_bytes)
+                            ptr, ready = self.ptrq.get()
+                            self.stream.wait_event(ready)  # the collective that last read this buffer has finished
+                            self.pred.copy_var_to_device("prob", ptr, p_bytes)
                             ev = torch.cuda.Event()
                             ev.record(self.stream)
                             self.doneq.put(ev)
@@ -275,7 +279,10 @@ def main():
             for s_ in range(n):
                 f_ = flights[s_ % P]
                 t_a = time.perf_counter()
-                f_.ptrq.put(gather.stage_buffer().data_ptr())
+                buf = gather.stage_buffer()  # main stream is now ordered behind the collective that last read `buf` ...
+                ready = torch.cuda.Event()
+                ready.record(main_stream)    # ... and the predictor's stream will be, through this event
+                f_.ptrq.put((buf.data_ptr(), ready))
                 t_b = time.perf_counter()
                 while True:
                     try:
@@ -316,6 +323,8 @@ def main():
                 # (device-to-device, on its own stream); the main stream waits for them and starts the asynchronous RCCL
                 # all_gather, which overlaps the next step (the buffer is waited for two steps later)
                 loc_ptr[0] = gather.stage_buffer().data_ptr()
+                loc_ready[0] = torch.cuda.Event()
+                loc_ready[0].record(main_stream)
                 for w_ in workers:
                     w_.go.release()
                 pred.copy_var_to_device("prob", loc_ptr[0], p_bytes)
