@@ -131,6 +131,9 @@ plhip_status plhip_dwpw_fused_int8(plhip_ctx* ctx, const plhip_conv_desc* dw, co
  * x [m,k] int8 row-major; w [k,n] int8 (Paddle "mul" layout); scale/bias per output column n.
  * Pre-pack (an opaque block of plhip_fc_packed_weight_bytes: a [k/4][n][4] copy for the dot4 kernels followed by the
  * MFMA A-fragment order, both zero padded) replaces the weight transpose of fc_compute.cc:53-62. */
+/* `relu` is a flag word: bit 0 = fused relu; bit 1 (fp32 output only) = round twice, float(acc)*scale then + bias, as
+ * the reference's gemm_s8 + fill_bias_fc route does (fc_compute.cc:250-266, taken there when m > 1 and the weight
+ * scale is a single value); without it the epilogue is the single fused multiply-add of its gemv route. */
 size_t plhip_fc_packed_weight_bytes(int k, int n);
 plhip_status plhip_pack_fc_weights(plhip_ctx* ctx, int k, int n, const int8_t* w_kn, void* w_packed);
 plhip_status plhip_fc_int8(plhip_ctx* ctx, int m, int k, int n, const int8_t* x, const void* w_packed,
@@ -147,6 +150,27 @@ plhip_status plhip_calib_i8_to_f32(plhip_ctx* ctx, const int8_t* x, float* y, fl
  * (lite/backends/arm/math/softmax.cc) for the tail pool2d -> calib -> fc -> softmax. */
 plhip_status plhip_global_avg_pool_f32(plhip_ctx* ctx, const float* x, int nc, int spatial, float* y);
 plhip_status plhip_softmax_f32(plhip_ctx* ctx, const float* x, int rows, int cols, float* y);
+
+/* ---- fp32 glue ops of the ResNet50 / MobileNetV2 programs (both ops are fp32-only on the
+ * reference's ARM target, so residual edges de/re-quantise through calib) ----
+ * pool2d replaces PoolCompute::Run (lite/kernels/arm/pool_compute.cc:36-345) -> pooling_basic and its specialisations
+ * (lite/backends/arm/math/pooling.cc:38-215): max, or avg with the exclusive flag, over windows clipped to the image;
+ * paddings {top, bottom, left, right}; output dims are the caller's (PoolOutputSize, lite/operators/pool_op.h, incl.
+ * ceil_mode).  x [n*c, h, w] -> y [n*c, oh, ow]. */
+typedef struct {
+  int planes, h, w, oh, ow;
+  int kh, kw;
+  int pad[4];
+  int stride[2];
+  int is_max;     /* 1 max, 0 avg */
+  int exclusive;  /* avg: divide by the clipped window size (pooling.cc:160-164) */
+} plhip_pool_desc;
+plhip_status plhip_pool2d_f32(plhip_ctx* ctx, const plhip_pool_desc* d, const float* x, float* y);
+/* elementwise_add / fusion_elementwise_add_activation(relu), same-shape operands: replaces ElementwiseAddCompute /
+ * ElementwiseAddActivationCompute (lite/kernels/arm/elementwise_compute.cc:85-140) -> elementwise_add{,_relu}<float>
+ * (lite/backends/arm/math/elementwise.cc).  out may alias x or y. */
+plhip_status plhip_elementwise_add_f32(plhip_ctx* ctx, const float* x, const float* y, float* out, int64_t count,
+                                       int relu);
 
 /* ---- introspection used by tests: operand-layout self-check of the MFMA tile on this device.
  * Runs a tiny known-answer GEMM through the MFMA path; returns PLHIP_OK iff bit-exact. ---- */

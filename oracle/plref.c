@@ -205,6 +205,19 @@ void plref_fc_epilogue_f32(const int32_t* acc, int m, int n, const float* scale,
                                                  bias ? bias[j] : 0.f, relu ? PLREF_ACT_RELU : 0, 0.f);
 }
 
+/* fc_compute.cc:250-266 + funcs.cc:24-108: product rounded, bias added (second rounding), relu. */
+void plref_fc_epilogue_f32_two_roundings(const int32_t* acc, int m, int n, const float* scale,
+                                         const float* bias, int relu, float* y) {
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j) {
+      volatile float p = (float)acc[(int64_t)i * n + j] * scale[j];
+      volatile float v = bias ? p + bias[j] : p;
+      float r = v;
+      if (relu) r = r > 0.f ? r : 0.f;
+      y[(int64_t)i * n + j] = r;
+    }
+}
+
 void plref_fc_epilogue_i8(const int32_t* acc, int m, int n, const float* scale, const float* bias,
                           int relu, int8_t* y) {
   for (int i = 0; i < m; ++i)
@@ -253,5 +266,71 @@ void plref_softmax_f32(const float* x, int rows, int cols, float* y) {
       s += yr[j];
     }
     for (int j = 0; j < cols; ++j) yr[j] = (float)(yr[j] / s);
+  }
+}
+
+/* pool_op.cc:44-61 */
+int plref_pool_out_size(int in, int k, int pad0, int pad1, int stride, int ceil_mode) {
+  if (!ceil_mode) return (in - k + pad0 + pad1) / stride + 1;
+  return (in - k + pad0 + pad1 + stride - 1) / stride + 1;
+}
+
+/* pooling.cc:38-215 (non-global, non-adaptive branch), loop for loop. */
+void plref_pool2d_f32(const float* x, int planes, int h, int w, int oh, int ow, int kh, int kw, int sh_, int sw_,
+                      const int pad[4], int is_max, int exclusive, float* y) {
+  const int pad_h = pad[0], pad_w = pad[2];
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < planes; ++c) {
+    const float* xin = x + (int64_t)c * h * w;
+    float* yo = y + (int64_t)c * oh * ow;
+    for (int ih = 0; ih < oh; ++ih) {
+      int sh = ih * sh_, eh = sh + kh;
+      sh = (sh - pad_h) < 0 ? 0 : sh - pad_h;
+      eh = (eh - pad_h) > h ? h : eh - pad_h;
+      for (int iw = 0; iw < ow; ++iw) {
+        int sw = iw * sw_, ew = sw + kw;
+        sw = (sw - pad_w) < 0 ? 0 : sw - pad_w;
+        ew = (ew - pad_w) > w ? w : ew - pad_w;
+        float result = 0.f;
+        for (int a = sh; a < eh; ++a)
+          for (int b = sw; b < ew; ++b) {
+            const float v = xin[a * w + b];
+            if (a == sh && b == sw) result = v;
+            else if (is_max) result = result >= v ? result : v;
+            else { volatile float t = result + v; result = t; }
+          }
+        if (!is_max) {
+          if (exclusive) {
+            int div = (ew - sw) * (eh - sh);
+            div = div > 0 ? div : 1;
+            result /= div;
+          } else {
+            int bh = kh, bw = kw;
+            if (ew == w) {
+              bw = (sw + kw) >= (w + pad[3]) ? (w + pad[3]) : (sw + kw);
+              bw -= sw;
+              if ((sw - pad_w) < 0 && (sw + kw) > (w + pad[3])) bw += pad_w;
+            }
+            if (eh == h) {
+              bh = (sh + kh) >= (h + pad[1]) ? (h + pad[1]) : (sh + kh);
+              bh -= sh;
+              if ((sh - pad_h) < 0 && (sh + kh) > (h + pad[1])) bh += pad_h;
+            }
+            result /= bh * bw;
+          }
+        }
+        yo[ih * ow + iw] = result;
+      }
+    }
+  }
+}
+
+/* elementwise.cc: elementwise_add<float> / elementwise_add_relu<float>. */
+void plref_elementwise_add_f32(const float* x, const float* y, float* out, int64_t count, int relu) {
+  for (int64_t i = 0; i < count; ++i) {
+    volatile float s = x[i] + y[i];
+    float r = s;
+    if (relu) r = r > 0.f ? r : 0.f;
+    out[i] = r;
   }
 }

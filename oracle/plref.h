@@ -85,6 +85,15 @@ void plref_apply_epilogue_i8(const int32_t* acc, int n, int cout, int spatial, c
 void plref_fc_i8_acc(int m, int n, int k, const int8_t* x, const int8_t* w, int32_t* acc);
 void plref_fc_epilogue_f32(const int32_t* acc, int m, int n, const float* scale, const float* bias,
                            int relu, float* y);
+/* The reference's fp32-out FC has two epilogue routes (fc_compute.cc:66-71, 229-290):
+ *   route 0  gemv_int8 per row (m == 1 or a per-column weight scale): vmlaq_f32(bias, float(acc), scale)
+ *            (gemv_arm_int8.cc:47-56), contracted to one fmla == plref_fc_epilogue_f32;
+ *   route 1  gemm_s8 without bias, then fill_bias_fc (m > 1 and a single weight scale): y = float(acc)*s rounded,
+ *            then y + b rounded again, then relu (fc_compute.cc:250-266, lite/backends/arm/math/funcs.cc:24-108;
+ *            also the scalar tail of write_gemv_out, gemv_arm_int8.cc:85-87).
+ * Route 1 differs from route 0 by at most half an ulp of the product plus one ulp of the result. */
+void plref_fc_epilogue_f32_two_roundings(const int32_t* acc, int m, int n, const float* scale,
+                                         const float* bias, int relu, float* y);
 void plref_fc_epilogue_i8(const int32_t* acc, int m, int n, const float* scale, const float* bias,
                           int relu, int8_t* y);
 
@@ -96,6 +105,17 @@ void plref_calib_i8_to_f32(const int8_t* x, float* y, float scale, int64_t count
  * lite/backends/arm/math/pooling.cc (pooling_global_avg), lite/backends/arm/math/softmax.cc. */
 void plref_global_avg_pool_f32(const float* x, int nc, int spatial, float* y);
 void plref_softmax_f32(const float* x, int rows, int cols, float* y);
+
+/* pool2d, fp32: lite/backends/arm/math/pooling.cc:38-215 (pooling_basic: windows clipped to the image, the first
+ * element initialises the result; avg: exclusive -> clipped window size, else the divisor of :165-205 as written).
+ * pad = {top, bottom, left, right}.  Output dims are the caller's (PoolOutputSize, lite/operators/pool_op.cc:44-61). */
+void plref_pool2d_f32(const float* x, int planes, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw,
+                      const int pad[4], int is_max, int exclusive, float* y);
+int plref_pool_out_size(int in, int k, int pad0, int pad1, int stride, int ceil_mode);
+
+/* elementwise_add / elementwise_add_relu <float>, same-shape operands: lite/backends/arm/math/elementwise.cc
+ * (vaddq_f32, then vmaxq_f32 with 0 for the fused relu). */
+void plref_elementwise_add_f32(const float* x, const float* y, float* out, int64_t count, int relu);
 
 /* round-half-away + saturate helpers exposed for host-side bit tricks tests. */
 int8_t plref_round_sat_i8(float v);

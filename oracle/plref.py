@@ -152,8 +152,14 @@ def gemm_acc(a, b):
     return c
 
 
-def fc(x, w, bias, scale, relu, int8_out):
-    """x [m,k] int8, w [k,n] int8, scale [n] (already folded), bias [n] or None."""
+def fc_route(m, n_weight_scale):
+    """The reference's dispatch (fc_compute.cc:66-71): gemm_s8 + fill_bias_fc (two roundings) iff m > 1 and a single
+    weight scale; gemv_int8 per row (one fused multiply-add) otherwise."""
+    return 1 if (m > 1 and n_weight_scale == 1) else 0
+
+
+def fc(x, w, bias, scale, relu, int8_out, route=0):
+    """x [m,k] int8, w [k,n] int8, scale [n] (already folded), bias [n] or None.  route: see fc_route()."""
     x = np.ascontiguousarray(x, np.int8)
     w = np.ascontiguousarray(w, np.int8)
     m, k = x.shape
@@ -170,7 +176,8 @@ def fc(x, w, bias, scale, relu, int8_out):
         lib().plref_fc_epilogue_i8(_p(acc, C.c_int32), m, n, _p(scale, C.c_float), bp, int(relu), _p(y, C.c_int8))
     else:
         y = np.empty((m, n), np.float32)
-        lib().plref_fc_epilogue_f32(_p(acc, C.c_int32), m, n, _p(scale, C.c_float), bp, int(relu), _p(y, C.c_float))
+        f = lib().plref_fc_epilogue_f32_two_roundings if route == 1 else lib().plref_fc_epilogue_f32
+        f(_p(acc, C.c_int32), m, n, _p(scale, C.c_float), bp, int(relu), _p(y, C.c_float))
     return y, acc
 
 
@@ -194,6 +201,28 @@ def global_avg_pool(x):
     y = np.empty((n, c, 1, 1), np.float32)
     lib().plref_global_avg_pool_f32(_p(x, C.c_float), n * c, int(np.prod(x.shape[2:])), _p(y, C.c_float))
     return y
+
+
+def pool2d(x, pooling_type, ksize, strides, pads, exclusive=True, ceil_mode=False):
+    """x [n,c,h,w] fp32; pads {top, bottom, left, right}."""
+    x = np.ascontiguousarray(x, np.float32)
+    n, c, h, w = x.shape
+    oh = lib().plref_pool_out_size(h, ksize[0], pads[0], pads[1], strides[0], int(ceil_mode))
+    ow = lib().plref_pool_out_size(w, ksize[1], pads[2], pads[3], strides[1], int(ceil_mode))
+    y = np.empty((n, c, oh, ow), np.float32)
+    pad = (C.c_int * 4)(*pads)
+    lib().plref_pool2d_f32(_p(x, C.c_float), n * c, h, w, oh, ow, ksize[0], ksize[1], strides[0], strides[1], pad,
+                           int(pooling_type == "max"), int(exclusive), _p(y, C.c_float))
+    return y
+
+
+def elementwise_add(x, y, relu=False):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    assert x.shape == y.shape
+    o = np.empty(x.shape, np.float32)
+    lib().plref_elementwise_add_f32(_p(x, C.c_float), _p(y, C.c_float), _p(o, C.c_float), C.c_int64(x.size), int(relu))
+    return o
 
 
 def softmax(x):

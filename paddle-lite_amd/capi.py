@@ -25,7 +25,7 @@ EXPORTS = [
     "plhip_conv2d_int8", "plhip_conv_impl_name", "plhip_depthwise_conv_int8", "plhip_dwpw_fused_int8",
     "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
     "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
-    "plhip_selftest",
+    "plhip_pool2d_f32", "plhip_elementwise_add_f32", "plhip_selftest",
 ]
 
 
@@ -34,6 +34,12 @@ class ConvDesc(C.Structure):
                 ("cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
                 ("pad", C.c_int * 4), ("stride", C.c_int * 2), ("dil", C.c_int * 2),
                 ("groups", C.c_int), ("act", C.c_int), ("act_alpha", C.c_float)]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [("planes", C.c_int), ("h", C.c_int), ("w", C.c_int), ("oh", C.c_int), ("ow", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("pad", C.c_int * 4), ("stride", C.c_int * 2),
+                ("is_max", C.c_int), ("exclusive", C.c_int)]
 
 
 def conv_desc(n, cin, h, w, cout, kh, kw, pad=(0, 0, 0, 0), stride=(1, 1), dil=(1, 1), groups=1,
@@ -110,6 +116,8 @@ def load():
     L.plhip_calib_i8_to_f32.argtypes = [vp, vp, vp, f32, C.c_int64]
     L.plhip_global_avg_pool_f32.argtypes = [vp, vp, i32, i32, vp]
     L.plhip_softmax_f32.argtypes = [vp, vp, i32, i32, vp]
+    L.plhip_pool2d_f32.argtypes = [vp, C.POINTER(PoolDesc), vp, vp]
+    L.plhip_elementwise_add_f32.argtypes = [vp, vp, vp, vp, C.c_int64, i32]
     L.plhip_selftest.argtypes = [vp]
     _lib = L
     return L
@@ -282,3 +290,34 @@ class Context:
         y = self.to_host(dy, x.shape, np.float32)
         self.free(dx), self.free(dy)
         return y
+
+    def pool2d(self, x, pooling_type, ksize, strides, pads, exclusive=True, ceil_mode=False):
+        """x [n,c,h,w] fp32; pads {top, bottom, left, right}; output dims by PoolOutputSize (pool_op.cc:44-61)."""
+        x = np.ascontiguousarray(x, np.float32)
+        n, c, h, w = x.shape
+
+        def osz(i, k, p0, p1, s):
+            return (i - k + p0 + p1 + (s - 1 if ceil_mode else 0)) // s + 1
+        d = PoolDesc()
+        d.planes, d.h, d.w = n * c, h, w
+        d.oh, d.ow = osz(h, ksize[0], pads[0], pads[1], strides[0]), osz(w, ksize[1], pads[2], pads[3], strides[1])
+        d.kh, d.kw = ksize
+        d.pad[:] = list(pads)
+        d.stride[:] = list(strides)
+        d.is_max, d.exclusive = int(pooling_type == "max"), int(exclusive)
+        dx = self.to_device(x)
+        dy = self.malloc(n * c * d.oh * d.ow * 4)
+        self.check(self.L.plhip_pool2d_f32(self.h, C.byref(d), dx, dy), "pool2d")
+        y = self.to_host(dy, (n, c, d.oh, d.ow), np.float32)
+        self.free(dx), self.free(dy)
+        return y
+
+    def elementwise_add(self, x, y, relu=False):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        dx, dy = self.to_device(x), self.to_device(y)
+        do = self.malloc(max(4, x.size * 4))
+        self.check(self.L.plhip_elementwise_add_f32(self.h, dx, dy, do, x.size, int(relu)), "elementwise_add")
+        o = self.to_host(do, x.shape, np.float32)
+        self.free(dx), self.free(dy), self.free(do)
+        return o

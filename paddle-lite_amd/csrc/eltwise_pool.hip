@@ -1,0 +1,115 @@
+// eltwise_pool.hip — the fp32 glue ops that sit between the int8 convs of the ResNet50 / MobileNetV2 programs
+// (SURVEY.md Appendix D): pool2d (max / avg windows) and elementwise_add (+ fused relu) for gfx950.
+//
+// Replaces (reference, ARM — both ops exist there in fp32 only, so residual edges de/re-quantise through calib):
+//   pool2d                              PoolCompute::Run lite/kernels/arm/pool_compute.cc:36-345 ->
+//                                       pooling_basic lite/backends/arm/math/pooling.cc:38-215 (semantics of every
+//                                       specialised pooling3x3s2p1_max etc.: max / sum over the window clipped to the image)
+//   elementwise_add                     ElementwiseAddCompute lite/kernels/arm/elementwise_compute.cc:85-110 ->
+//                                       elementwise_add<float> lite/backends/arm/math/elementwise.cc
+//   fusion_elementwise_add_activation   ElementwiseAddActivationCompute (:112-140) -> elementwise_add_relu<float>
+// Both are pure HBM streams: 16 bytes per lane, no LDS.
+#include "plhip_device.h"
+#include "plhip_kernels.h"
+
+namespace plhip {
+
+// One lane = 4 consecutive outputs of one output row.  Grid: x = quads of a row x rows (flattened), y = planes, so
+// plane / row / validity of a window row are cheap.  Window rows and columns are clipped to the image exactly as
+// pooling_basic does (sh/eh/sw/ew), the first valid element initialises the result.
+template <bool MAX>
+__global__ __launch_bounds__(256) void pool2d_f32_kernel(PoolArgs a) {
+  const int owq = (a.ow + 3) >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= owq * a.oh) return;
+  const int oy = idx / owq, oxq = idx - oy * owq;
+  const size_t plane = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
+  if (plane >= (size_t)a.planes) return;
+  const float* __restrict__ xp = a.x + plane * (size_t)a.h * a.w;
+  float* __restrict__ yp = a.y + plane * (size_t)a.oh * a.ow + (size_t)oy * a.ow;
+  int sh = oy * a.sh - a.pt, eh = sh + a.kh;
+  sh = sh < 0 ? 0 : sh;
+  eh = eh > a.h ? a.h : eh;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ox = oxq * 4 + j;
+    if (ox >= a.ow) break;
+    int sw = ox * a.sw - a.pl, ew = sw + a.kw;
+    sw = sw < 0 ? 0 : sw;
+    ew = ew > a.w ? a.w : ew;
+    float r = 0.f;
+    bool first = true;
+    for (int y = sh; y < eh; ++y)
+      for (int x = sw; x < ew; ++x) {
+        const float v = xp[(size_t)y * a.w + x];
+        if (first) { r = v; first = false; }
+        else if (MAX) r = r >= v ? r : v;
+        else r += v;
+      }
+    if (!MAX) {
+      if (a.exclusive) {
+        int div = (ew - sw) * (eh - sh);
+        div = div > 0 ? div : 1;
+        r /= (float)div;
+      } else {
+        // pooling.cc:165-205 as written (sw / sh are the CLIPPED window starts there): the full kernel area unless
+        // the window touches the right / bottom image edge, where the covered padding is counted
+        int bh = a.kh, bw = a.kw;
+        if (ew == a.w) {
+          bw = (sw + a.kw) >= (a.w + a.pr) ? (a.w + a.pr) : (sw + a.kw);
+          bw -= sw;
+          if ((sw - a.pl) < 0 && (sw + a.kw) > (a.w + a.pr)) bw += a.pl;
+        }
+        if (eh == a.h) {
+          bh = (sh + a.kh) >= (a.h + a.pb) ? (a.h + a.pb) : (sh + a.kh);
+          bh -= sh;
+          if ((sh - a.pt) < 0 && (sh + a.kh) > (a.h + a.pb)) bh += a.pt;
+        }
+        r /= (float)(bh * bw);
+      }
+    }
+    yp[ox] = r;
+  }
+}
+
+void launch_pool2d(const PoolArgs& a, hipStream_t s) {
+  const int owq = (a.ow + 3) >> 2;
+  const int gy = a.planes < 32768 ? a.planes : 32768;
+  dim3 grid((owq * a.oh + 255) / 256, gy, (a.planes + gy - 1) / gy);
+  if (a.is_max) hipLaunchKernelGGL((pool2d_f32_kernel<true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((pool2d_f32_kernel<false>), grid, dim3(256), 0, s, a);
+}
+
+// out = x + y  (then max(., 0) when relu): elementwise.cc elementwise_add / elementwise_add_relu, same-shape operands.
+template <bool RELU>
+__global__ __launch_bounds__(256) void eltwise_add_f32_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              float* __restrict__ o, int64_t count, int vec) {
+  const int64_t nq = vec ? count >> 2 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
+    const v4f a = reinterpret_cast<const v4f*>(x)[i], b = reinterpret_cast<const v4f*>(y)[i];
+    v4f r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[j] = a[j] + b[j];
+      if (RELU) r[j] = r[j] > 0.f ? r[j] : 0.f;
+    }
+    reinterpret_cast<v4f*>(o)[i] = r;
+  }
+  for (int64_t t = (nq << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
+    float r = x[t] + y[t];
+    if (RELU) r = r > 0.f ? r : 0.f;
+    o[t] = r;
+  }
+}
+
+void launch_eltwise_add(const float* x, const float* y, float* o, int64_t count, int relu, hipStream_t s) {
+  const int vec = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)o) & 15) == 0) ? 1 : 0;
+  int64_t b = ((vec ? count >> 2 : count) + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 8192) b = 8192;
+  if (relu) hipLaunchKernelGGL((eltwise_add_f32_kernel<true>), dim3((unsigned)b), dim3(256), 0, s, x, y, o, count, vec);
+  else hipLaunchKernelGGL((eltwise_add_f32_kernel<false>), dim3((unsigned)b), dim3(256), 0, s, x, y, o, count, vec);
+}
+
+}  // namespace plhip

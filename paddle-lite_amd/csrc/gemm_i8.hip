@@ -897,6 +897,10 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
   const bool use_dma = g.im_kw > 0 ||  // the implicit-GEMM route exists only in the ring kernel (conv_geom checked the shape)
                        (g.HWX >= 16 && g.KS >= 4 && (var == 3 || (var == 0 && g.MT >= 4 && (MA == 2 || g.KS >= 8))));
   if (use_dma) {
+    // dense NCHW slabs whose rows are not a multiple of 4 bytes (HW = 49: the 7x7 layers) arrive with HWX rounded up to 4
+    // for the dword kernels; this kernel moves END-aligned 16-byte pieces and must know the TRUE row length, or the last
+    // piece of a row reaches HWX - XP bytes into the next row -- and past the end of the tensor on its last row
+    if (g.im_kw == 0 && g.XP > 0 && g.XP < g.HWX) g.HWX = g.XP;
     g.NT = (int)(((long)g.NB * ((g.HWX + 15) & ~15) + 127) / 128);  // 16-byte padded column space of this kernel
     const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
     static int areg_env = -1;

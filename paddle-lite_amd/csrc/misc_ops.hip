@@ -15,6 +15,15 @@
 
 namespace plhip {
 
+// FC epilogue.  flags bit 0: relu; bit 1: the reference's gemm_s8 + fill_bias_fc route (fc_compute.cc:250-266,
+// funcs.cc:24-108: product rounded, then the bias added with a second rounding) instead of the single fused
+// multiply-add of its gemv route (gemv_arm_int8.cc:47-56).  The host picks the route like check_fc_use_gemm does.
+__device__ __forceinline__ float fc_epilogue_f32(int acc, float s, float b, int flags) {
+  float y = (flags & 2) ? __fadd_rn(__fmul_rn((float)acc, s), b) : __fmaf_rn((float)acc, s, b);
+  if (flags & 1) y = y > 0.f ? y : 0.f;
+  return y;
+}
+
 // w [k][n] -> wp [(k+3)/4][n][4]  (zero padded in k)
 __global__ void pack_fc_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp, int k, int n) {
   const int k4n = (k + 3) / 4;
@@ -70,8 +79,7 @@ __global__ __launch_bounds__(256) void fc_i8_kernel(const int8_t* __restrict__ x
     if (OUT == OUT_I32) {
       reinterpret_cast<int*>(y)[off] = acc[i];
     } else {
-      // fp32-out spec: fma(float(acc), s, b) then relu
-      const float f = epilogue_f32(acc[i], s, bi, relu ? ACT_RELU : ACT_NONE, 0.f);
+      const float f = fc_epilogue_f32(acc[i], s, bi, relu);
       if (OUT == OUT_F32) reinterpret_cast<float*>(y)[off] = f;
       else reinterpret_cast<int8_t*>(y)[off] = (int8_t)round_sat_i8(f);
     }
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void fc_i8_fast_kernel(const int8_t* __restric
     if (OUT == OUT_I32) {
       reinterpret_cast<int*>(y)[off] = a;
     } else {
-      const float f = epilogue_f32(a, s, bi, relu ? ACT_RELU : ACT_NONE, 0.f);
+      const float f = fc_epilogue_f32(a, s, bi, relu);
       if (OUT == OUT_F32) reinterpret_cast<float*>(y)[off] = f;
       else reinterpret_cast<int8_t*>(y)[off] = (int8_t)round_sat_i8(f);
     }
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256) void fc_i8_mfma_kernel(const int8_t* __restric
   for (int e = 0; e < 4; ++e) {
     const int r = 4 * wave + e;
     a4[e] = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
-    f[e] = epilogue_f32(a4[e], sc4[e], bi4[e], relu ? ACT_RELU : ACT_NONE, 0.f);  // fp32-out spec
+    f[e] = fc_epilogue_f32(a4[e], sc4[e], bi4[e], relu);  // fp32-out spec
   }
   const size_t off = (size_t)mcol * n + n0;
   const int cnt = n - n0 < 4 ? n - n0 : 4;

@@ -583,6 +583,35 @@ plhip_status plhip_softmax_f32(plhip_ctx* ctx, const float* x, int rows, int col
   return PLHIP_OK;
 }
 
+plhip_status plhip_pool2d_f32(plhip_ctx* ctx, const plhip_pool_desc* d, const float* x, float* y) {
+  if (!ctx || !d || !x || !y) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pool2d_f32: null argument");
+  if (d->planes < 1 || d->h < 1 || d->w < 1 || d->oh < 1 || d->ow < 1 || d->kh < 1 || d->kw < 1 || d->stride[0] < 1 ||
+      d->stride[1] < 1 || d->pad[0] < 0 || d->pad[1] < 0 || d->pad[2] < 0 || d->pad[3] < 0)
+    return fail(ctx, PLHIP_ERR_INVALID, "plhip_pool2d_f32: bad descriptor");
+  // every window must start inside the padded image (PoolOutputSize guarantees it, ceil_mode included; windows that
+  // only cover padding yield 0 like pooling_basic)
+  if ((d->oh - 1) * d->stride[0] - d->pad[0] >= d->h + d->pad[1] || (d->ow - 1) * d->stride[1] - d->pad[2] >= d->w + d->pad[3])
+    return fail(ctx, PLHIP_ERR_INVALID, "plhip_pool2d_f32: output dims do not match the window geometry");
+  if ((size_t)d->h * d->w >= ((size_t)1 << 31) || (size_t)d->oh * d->ow >= ((size_t)1 << 31))
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_pool2d_f32: plane too large");
+  plhip::PoolArgs a;
+  a.x = x; a.y = y;
+  a.planes = d->planes; a.h = d->h; a.w = d->w; a.oh = d->oh; a.ow = d->ow; a.kh = d->kh; a.kw = d->kw;
+  a.sh = d->stride[0]; a.sw = d->stride[1]; a.pt = d->pad[0]; a.pb = d->pad[1]; a.pl = d->pad[2]; a.pr = d->pad[3];
+  a.is_max = d->is_max ? 1 : 0; a.exclusive = d->exclusive ? 1 : 0;
+  plhip::launch_pool2d(a, ctx->stream);
+  LAUNCHCHK(ctx, "pool2d");
+  return PLHIP_OK;
+}
+
+plhip_status plhip_elementwise_add_f32(plhip_ctx* ctx, const float* x, const float* y, float* out, int64_t count, int relu) {
+  if (!ctx || !x || !y || !out || count < 0) return fail(ctx, PLHIP_ERR_INVALID, "plhip_elementwise_add_f32: bad argument");
+  if (count == 0) return PLHIP_OK;
+  plhip::launch_eltwise_add(x, y, out, count, relu, ctx->stream);
+  LAUNCHCHK(ctx, "elementwise_add");
+  return PLHIP_OK;
+}
+
 // ------------------------------------------------------------------ self test
 // Known-answer 1x1 conv (M = 70, K = 45, N = 2 x 36) with asymmetric data, int32 accumulators compared with a host
 // triple loop: proves the MFMA operand / accumulator lane maps and the in-register transpose on this device.

@@ -112,4 +112,14 @@ void launch_calib_i8_to_f32(const int8_t* x, float* y, float scale, int64_t coun
 void launch_global_avg_pool(const float* x, int nc, int spatial, float* y, hipStream_t s);
 void launch_softmax(const float* x, int rows, int cols, float* y, hipStream_t s);
 
+// fp32 window pooling (max / avg) and elementwise add (+relu): eltwise_pool.hip
+struct PoolArgs {
+  const float* x;  // [planes][h][w]
+  float* y;        // [planes][oh][ow]
+  int planes, h, w, oh, ow, kh, kw, sh, sw, pt, pb, pl, pr;
+  int is_max, exclusive;
+};
+void launch_pool2d(const PoolArgs& a, hipStream_t s);
+void launch_eltwise_add(const float* x, const float* y, float* o, int64_t count, int relu, hipStream_t s);
+
 }  // namespace plhip

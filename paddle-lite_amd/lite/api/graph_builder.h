@@ -1,0 +1,80 @@
+// graph_builder.h — from an op list "as the optimiser sees it after the fusion passes" to the kHIP RuntimeProgram.
+//
+// The reference builds its program with ~60 MIR passes; the model parser and the generic optimiser are
+// out of scope.  What decides WHICH int8 kernels run and WHERE precision casts sit is restated here, in the order the
+// reference applies it (lite/api/cxx_api.cc / lite/core/optimizer.h pass list):
+//   1. static_kernel_pick_pass (lite/core/mir/static_kernel_pick_pass.cc:92-165): an enable_int8 op takes the
+//      int8-output kernel iff EVERY consumer of its output is enable_int8, and then inherits the first consumer's
+//      input scale as its output scale; otherwise the fp32-output kernel.
+//   2. type_target_cast_pass: io_copy host->device behind every feed, device->host in front of every fetch.
+//   3. type_precision_cast_pass (lite/core/mir/type_precision_cast_pass.cc:60-100, 130-260): where a consumer's declared
+//      input precision differs from the tensor's, a calib op is inserted; one calib per source tensor, shared by later
+//      consumers (`cast_nodes`); its scale is the consumer's input scale (fp32->int8) or the producer's output scale
+//      (int8->fp32); its output is named "<var>/precision_trans".
+// Ops arrive in topological order with the conv+bn, conv+activation, fc and elementwise_add+activation fusions already
+// applied (the model loader, lite/model_parser of this repo, does the weight-side part of those).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "lite/api/hip_predictor.h"
+
+namespace paddle {
+namespace lite {
+
+struct GraphOp {
+  std::string type;  // conv2d | depthwise_conv2d | fc | pool2d | elementwise_add | fusion_elementwise_add_activation | softmax
+  std::vector<std::string> inputs;
+  std::string output;
+  bool enable_int8{false};
+  // conv2d / depthwise_conv2d / fc
+  std::vector<int8_t> w;
+  std::vector<int64_t> w_dims;
+  std::vector<float> bias;
+  bool has_bias{false};
+  ConvAttrs conv;  // input_scale, weight_scale, act, strides ...; output_scale / int8_out are set by Lower()
+  bool fc_relu{false};
+  // pool2d
+  std::string pooling_type{"max"};
+  std::vector<int> ksize{1, 1}, pool_strides{1, 1}, pool_paddings{0, 0, 0, 0};
+  bool global_pooling{false}, exclusive{true}, ceil_mode{false};
+  // fusion_elementwise_add_activation
+  std::string act_type;
+};
+
+class GraphBuilder {
+ public:
+  void Feed(const std::string& name, const std::vector<int64_t>& dims, PrecisionType prec);
+  void Fetch(const std::string& name) { fetches_.push_back(name); }
+  GraphOp& Add(const std::string& type, const std::vector<std::string>& inputs, const std::string& output);
+  // Emits the program into `pred`; returns the host-side names of the fetched variables ("<name>/host").
+  std::vector<std::string> Lower(HipPredictor* pred);
+  // The decisions of passes 1-3 as text, one instruction per line (CPU-testable without a device):
+  //   "conv2d/int8_out in=a out=b oscale=0.031496"   "calib/fp32_to_int8 in=x out=x/precision_trans scale=..."
+  std::vector<std::string> Plan();
+
+ private:
+  struct Step {
+    int op{-1};              // index into ops_, or -1 for an inserted instruction
+    std::string kind;        // "op", "io_copy_h2d", "io_copy_d2h", "calib_f2i", "calib_i2f"
+    std::string in, out;
+    float scale{0.f};
+    bool int8_out{false};
+    float out_scale{1.f};
+    std::vector<std::string> op_inputs;  // op inputs after cast renaming
+  };
+  std::vector<Step> Schedule();
+  struct FeedDesc {
+    std::string name;
+    std::vector<int64_t> dims;
+    PrecisionType prec;
+  };
+  std::vector<FeedDesc> feeds_;
+  std::vector<std::string> fetches_;
+  std::vector<GraphOp> ops_;
+};
+
+}  // namespace lite
+}  // namespace paddle

@@ -121,6 +121,43 @@ void HipPredictor::AddGlobalAvgPool(const std::string& in, const std::string& ou
   Emit(op, PickKernel("pool2d", Place(TARGET(kHIP), PRECISION(kFloat)), "def"));
 }
 
+void HipPredictor::AddPool(const std::string& in, const std::string& out, const std::string& pooling_type,
+                           const std::vector<int>& ksize, const std::vector<int>& strides, const std::vector<int>& paddings,
+                           bool global_pooling, bool exclusive, bool ceil_mode) {
+  auto op = std::make_shared<operators::PoolOpLite>();
+  auto& p = op->mutable_param();
+  p.x = Var(in);
+  p.output = Var(out);
+  p.pooling_type = pooling_type;
+  p.ksize = ksize;
+  p.strides = strides;
+  p.global_pooling = global_pooling;
+  p.exclusive = exclusive;
+  p.ceil_mode = ceil_mode;
+  p.paddings = std::make_shared<std::vector<int>>(paddings);
+  Emit(op, PickKernel("pool2d", Place(TARGET(kHIP), PRECISION(kFloat)), "def"));
+}
+
+void HipPredictor::AddElementwiseAdd(const std::string& x, const std::string& y, const std::string& out,
+                                     const std::string& act_type) {
+  if (act_type.empty()) {
+    auto op = std::make_shared<operators::ElementwiseOp>("elementwise_add");
+    auto& p = op->mutable_param();
+    p.X = Var(x);
+    p.Y = Var(y);
+    p.Out = Var(out);
+    Emit(op, PickKernel("elementwise_add", Place(TARGET(kHIP), PRECISION(kFloat)), "def"));
+  } else {
+    auto op = std::make_shared<operators::FusionElementwiseActivationOp>("fusion_elementwise_add_activation");
+    auto& p = op->mutable_param();
+    p.X = Var(x);
+    p.Y = Var(y);
+    p.Out = Var(out);
+    p.act_type = act_type;
+    Emit(op, PickKernel("fusion_elementwise_add_activation", Place(TARGET(kHIP), PRECISION(kFloat)), "def"));
+  }
+}
+
 void HipPredictor::AddSoftmax(const std::string& in, const std::string& out) {
   auto op = std::make_shared<operators::SoftmaxOp>();
   op->mutable_param().x = Var(in);

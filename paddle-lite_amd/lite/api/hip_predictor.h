@@ -48,6 +48,11 @@ class HipPredictor {
   void AddFc(const std::string& in, const std::string& out, const int8_t* w, int k, int n, const float* bias,
              float input_scale, const std::vector<float>& weight_scale, float output_scale, bool int8_out, bool relu);
   void AddGlobalAvgPool(const std::string& in, const std::string& out);
+  void AddPool(const std::string& in, const std::string& out, const std::string& pooling_type, const std::vector<int>& ksize,
+               const std::vector<int>& strides, const std::vector<int>& paddings, bool global_pooling, bool exclusive,
+               bool ceil_mode);
+  // act_type "" -> elementwise_add, "relu" -> fusion_elementwise_add_activation
+  void AddElementwiseAdd(const std::string& x, const std::string& y, const std::string& out, const std::string& act_type);
   void AddSoftmax(const std::string& in, const std::string& out);
 
   void Run(bool skip_io_copy = false) {

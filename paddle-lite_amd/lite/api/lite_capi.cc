@@ -4,6 +4,7 @@
 #include <cstring>
 #include <string>
 
+#include "lite/api/graph_builder.h"
 #include "lite/api/hip_predictor.h"
 
 using paddle::lite::HipPredictor;
@@ -12,6 +13,7 @@ using paddle::lite::Tensor;
 struct pllite_predictor {
   explicit pllite_predictor(int dev) : pred(dev) {}
   HipPredictor pred;
+  paddle::lite::GraphBuilder graph;
 };
 
 namespace {
@@ -101,6 +103,106 @@ int pllite_add_global_avg_pool(pllite_predictor* p, const char* in, const char* 
 int pllite_add_softmax(pllite_predictor* p, const char* in, const char* out) {
   return guarded([&] { p->pred.AddSoftmax(in, out); });
 }
+int pllite_add_pool(pllite_predictor* p, const char* in, const char* out, const char* pooling_type, const int* ksize,
+                    const int* strides, const int* pads, int global_pooling, int exclusive, int ceil_mode) {
+  return guarded([&] {
+    p->pred.AddPool(in, out, pooling_type, {ksize[0], ksize[1]}, {strides[0], strides[1]},
+                    {pads[0], pads[1], pads[2], pads[3]}, global_pooling != 0, exclusive != 0, ceil_mode != 0);
+  });
+}
+int pllite_add_elementwise_add(pllite_predictor* p, const char* x, const char* y, const char* out, const char* act_type) {
+  return guarded([&] { p->pred.AddElementwiseAdd(x, y, out, act_type ? act_type : ""); });
+}
+
+// ---- graph mode
+pllite_predictor* pllite_predictor_create_planner(void) {
+  pllite_predictor* p = nullptr;
+  if (guarded([&] { p = new pllite_predictor(0); }) != 0) return nullptr;
+  return p;
+}
+int pllite_graph_feed(pllite_predictor* p, const char* name, const int64_t* dims, int ndims, int precision) {
+  return guarded([&] {
+    p->graph.Feed(name, std::vector<int64_t>(dims, dims + ndims), static_cast<paddle::lite::PrecisionType>(precision));
+  });
+}
+int pllite_graph_conv(pllite_predictor* p, const char* op_type, const char* in, const char* out, const int8_t* w,
+                      const int64_t* w_dims, const float* bias, const int* strides, const int* paddings, int n_paddings,
+                      const int* dilations, int groups, int act, float act_coef, float input_scale,
+                      const float* weight_scale, int n_weight_scale, const char* padding_algorithm) {
+  return guarded([&] {
+    auto& op = p->graph.Add(op_type, {in}, out);
+    op.enable_int8 = true;
+    op.w_dims.assign(w_dims, w_dims + 4);
+    size_t wn = 1;
+    for (auto d : op.w_dims) wn *= static_cast<size_t>(d);
+    op.w.assign(w, w + wn);
+    op.has_bias = bias != nullptr;
+    if (bias) op.bias.assign(bias, bias + w_dims[0]);
+    auto& a = op.conv;
+    a.strides = {strides[0], strides[1]};
+    a.paddings.assign(paddings, paddings + n_paddings);
+    a.dilations = {dilations[0], dilations[1]};
+    a.groups = groups;
+    a.act = act;
+    a.act_coef = act_coef;
+    a.input_scale = input_scale;
+    a.weight_scale.assign(weight_scale, weight_scale + n_weight_scale);
+    a.padding_algorithm = padding_algorithm ? padding_algorithm : "";
+  });
+}
+int pllite_graph_fc(pllite_predictor* p, const char* in, const char* out, const int8_t* w, int k, int n, const float* bias,
+                    float input_scale, const float* weight_scale, int n_ws, int relu) {
+  return guarded([&] {
+    auto& op = p->graph.Add("fc", {in}, out);
+    op.enable_int8 = true;
+    op.w_dims = {k, n};
+    op.w.assign(w, w + static_cast<size_t>(k) * n);
+    op.has_bias = bias != nullptr;
+    if (bias) op.bias.assign(bias, bias + n);
+    op.conv.input_scale = input_scale;
+    op.conv.weight_scale.assign(weight_scale, weight_scale + n_ws);
+    op.fc_relu = relu != 0;
+  });
+}
+int pllite_graph_pool(pllite_predictor* p, const char* in, const char* out, const char* pooling_type, const int* ksize,
+                      const int* strides, const int* pads, int global_pooling, int exclusive, int ceil_mode) {
+  return guarded([&] {
+    auto& op = p->graph.Add("pool2d", {in}, out);
+    op.pooling_type = pooling_type;
+    op.ksize = {ksize[0], ksize[1]};
+    op.pool_strides = {strides[0], strides[1]};
+    op.pool_paddings = {pads[0], pads[1], pads[2], pads[3]};
+    op.global_pooling = global_pooling != 0;
+    op.exclusive = exclusive != 0;
+    op.ceil_mode = ceil_mode != 0;
+  });
+}
+int pllite_graph_elementwise_add(pllite_predictor* p, const char* x, const char* y, const char* out, const char* act_type) {
+  return guarded([&] {
+    const std::string act = act_type ? act_type : "";
+    auto& op = p->graph.Add(act.empty() ? "elementwise_add" : "fusion_elementwise_add_activation", {x, y}, out);
+    op.act_type = act;
+  });
+}
+int pllite_graph_softmax(pllite_predictor* p, const char* in, const char* out) {
+  return guarded([&] { p->graph.Add("softmax", {in}, out); });
+}
+int pllite_graph_fetch(pllite_predictor* p, const char* name) {
+  return guarded([&] { p->graph.Fetch(name); });
+}
+static void join_lines(const std::vector<std::string>& v, char* buf, int cap) {
+  std::string s;
+  for (auto& n : v) s += n + "\n";
+  CHECK_LT(static_cast<int>(s.size()), cap) << "buffer too small";
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+}
+int pllite_graph_plan(pllite_predictor* p, char* buf, int cap) {
+  return guarded([&] { join_lines(p->graph.Plan(), buf, cap); });
+}
+int pllite_graph_lower(pllite_predictor* p, char* buf, int cap) {
+  return guarded([&] { join_lines(p->graph.Lower(&p->pred), buf, cap); });
+}
+
 int pllite_set_input(pllite_predictor* p, const char* name, const void* host, int64_t bytes) {
   return guarded([&] {
     CHECK(p->pred.HasVar(name)) << "unknown variable " << name;

@@ -31,6 +31,32 @@ int pllite_add_fc(pllite_predictor* p, const char* in, const char* out, const in
                   int relu);
 int pllite_add_global_avg_pool(pllite_predictor* p, const char* in, const char* out);
 int pllite_add_softmax(pllite_predictor* p, const char* in, const char* out);
+int pllite_add_pool(pllite_predictor* p, const char* in, const char* out, const char* pooling_type, const int* ksize,
+                    const int* strides, const int* paddings4, int global_pooling, int exclusive, int ceil_mode);
+int pllite_add_elementwise_add(pllite_predictor* p, const char* x, const char* y, const char* out, const char* act_type);
+
+/* ---- graph mode (lite/api/graph_builder.h): ops as the optimiser sees them after its fusion passes; kernel choice
+ * (int8_out / fp32_out), io_copy and calib placement are decided by pllite_graph_lower() with the reference's rules.
+ * One graph per predictor; ops in topological order. ---- */
+int pllite_graph_feed(pllite_predictor* p, const char* name, const int64_t* dims, int ndims, int precision);
+int pllite_graph_conv(pllite_predictor* p, const char* op_type, const char* in, const char* out, const int8_t* w,
+                      const int64_t* w_dims, const float* bias, const int* strides, const int* paddings, int n_paddings,
+                      const int* dilations, int groups, int act, float act_coef, float input_scale,
+                      const float* weight_scale, int n_weight_scale, const char* padding_algorithm);
+int pllite_graph_fc(pllite_predictor* p, const char* in, const char* out, const int8_t* w, int k, int n, const float* bias,
+                    float input_scale, const float* weight_scale, int n_weight_scale, int relu);
+int pllite_graph_pool(pllite_predictor* p, const char* in, const char* out, const char* pooling_type, const int* ksize,
+                      const int* strides, const int* paddings4, int global_pooling, int exclusive, int ceil_mode);
+int pllite_graph_elementwise_add(pllite_predictor* p, const char* x, const char* y, const char* out, const char* act_type);
+int pllite_graph_softmax(pllite_predictor* p, const char* in, const char* out);
+int pllite_graph_fetch(pllite_predictor* p, const char* name);
+/* '\n'-separated plan (GraphBuilder::Plan) — needs no device. */
+int pllite_graph_plan(pllite_predictor* p, char* buf, int cap);
+/* Emit the program into the predictor; '\n'-separated host names of the fetched variables in buf. */
+int pllite_graph_lower(pllite_predictor* p, char* buf, int cap);
+/* A predictor object that can only plan (no device needed): for CPU tests of the lowering rules. */
+pllite_predictor* pllite_predictor_create_planner(void);
+
 int pllite_set_input(pllite_predictor* p, const char* name, const void* host, int64_t bytes);
 int pllite_run(pllite_predictor* p, int skip_io_copy);
 int pllite_sync(pllite_predictor* p);

@@ -148,20 +148,113 @@ class IoCopyOp : public OpLite {
   mutable IoCopyParam param_;
 };
 
+// pool_op.cc:44-61
+inline int PoolOutputSize(int input_size, int filter_size, int pad_left, int pad_right, int stride, bool ceil_mode) {
+  if (!ceil_mode) return (input_size - filter_size + pad_left + pad_right) / stride + 1;
+  return (input_size - filter_size + pad_left + pad_right + stride - 1) / stride + 1;
+}
+
+// pool_op.h:119-150
+inline void UpdatePoolPadding(std::vector<int>* paddings, bool global_pooling, bool adaptive,
+                              const std::string& padding_algorithm, const DDim& data_dims,
+                              const std::vector<int>& strides, const std::vector<int>& ksize) {
+  if (padding_algorithm == "SAME") {
+    for (size_t i = 0; i < strides.size(); ++i) {
+      const int out_size = static_cast<int>((data_dims[i + 2] + strides[i] - 1) / strides[i]);
+      const int pad_sum =
+          static_cast<int>(std::max<int64_t>((out_size - 1) * strides[i] + ksize[i] - data_dims[i + 2], 0));
+      (*paddings)[i * 2] = pad_sum / 2;
+      (*paddings)[i * 2 + 1] = pad_sum - pad_sum / 2;
+    }
+  } else if (padding_algorithm == "VALID") {
+    for (auto& p : *paddings) p = 0;
+  }
+  if (global_pooling || adaptive)
+    for (auto& p : *paddings) p = 0;
+}
+
 class PoolOpLite : public OpLite {
  public:
   PoolOpLite() : OpLite("pool2d") {}
   PoolParam& mutable_param() { return param_; }
-  bool InferShapeImpl() const override {
+  void set_padding_algorithm(const std::string& a) { padding_algorithm_ = a; }
+  bool CheckShape() const override {
+    CHECK(param_.x && param_.output && param_.paddings);
+    CHECK_EQ(param_.x->dims().size(), 4UL) << "pool2d input must be NCHW";
+    if (param_.paddings->size() == 2UL) {  // pool_op.h AttachKernel: 2-element paddings -> {top, bottom, left, right}
+      const int ph = (*param_.paddings)[0], pw = (*param_.paddings)[1];
+      *param_.paddings = {ph, ph, pw, pw};
+    }
+    CHECK_EQ(param_.paddings->size(), 4UL);
+    if (!param_.global_pooling) {
+      CHECK_EQ(param_.ksize.size(), 2UL);
+      CHECK_EQ(param_.strides.size(), 2UL);
+    }
+    return true;
+  }
+  bool InferShapeImpl() const override {  // pool_op.cc:63-98
     const auto in = param_.x->dims();
-    CHECK(param_.global_pooling) << "only global pooling is on the int8 hot path";
-    param_.output->Resize({in[0], in[1], 1, 1});
+    UpdatePoolPadding(param_.paddings.get(), param_.global_pooling, param_.adaptive, padding_algorithm_, in,
+                      param_.strides, param_.ksize);
+    if (param_.global_pooling) {
+      param_.ksize.resize(2);
+      param_.ksize[0] = static_cast<int>(in[2]);
+      param_.ksize[1] = static_cast<int>(in[3]);
+    }
+    CHECK(!param_.adaptive) << "adaptive pooling is not on the int8 hot path";
+    std::vector<int64_t> out{in[0], in[1]};
+    for (size_t i = 0; i < 2; ++i)
+      out.push_back(PoolOutputSize(static_cast<int>(in[i + 2]), param_.ksize[i], (*param_.paddings)[2 * i],
+                                   (*param_.paddings)[2 * i + 1], param_.strides[i], param_.ceil_mode));
+    param_.output->Resize(out);
     return true;
   }
   void AttachKernel(KernelBase* k) override { k->SetParam<PoolParam>(param_); }
 
  private:
   mutable PoolParam param_;
+  std::string padding_algorithm_{""};
+};
+
+// elementwise_ops.cc: Out takes X's dims (same-shape operands on this path; Y broadcast along `axis` is not needed
+// by the residual adds of ResNet50 / MobileNetV2)
+class ElementwiseOp : public OpLite {
+ public:
+  explicit ElementwiseOp(const std::string& type = "elementwise_add") : OpLite(type) {}
+  ElementwiseParam& mutable_param() { return param_; }
+  bool CheckShape() const override {
+    CHECK(param_.X && param_.Y && param_.Out);
+    return true;
+  }
+  bool InferShapeImpl() const override {
+    CHECK(param_.X->dims() == param_.Y->dims()) << op_type_ << ": operands must have the same shape on kHIP";
+    param_.Out->Resize(param_.X->dims());
+    return true;
+  }
+  void AttachKernel(KernelBase* k) override { k->SetParam<ElementwiseParam>(param_); }
+
+ private:
+  mutable ElementwiseParam param_;
+};
+
+// fusion_elementwise_activation_ops.cc
+class FusionElementwiseActivationOp : public OpLite {
+ public:
+  explicit FusionElementwiseActivationOp(const std::string& type = "fusion_elementwise_add_activation") : OpLite(type) {}
+  FusionElementwiseActivationParam& mutable_param() { return param_; }
+  bool CheckShape() const override {
+    CHECK(param_.X && param_.Y && param_.Out);
+    return true;
+  }
+  bool InferShapeImpl() const override {
+    CHECK(param_.X->dims() == param_.Y->dims()) << op_type_ << ": operands must have the same shape on kHIP";
+    param_.Out->Resize(param_.X->dims());
+    return true;
+  }
+  void AttachKernel(KernelBase* k) override { k->SetParam<FusionElementwiseActivationParam>(param_); }
+
+ private:
+  mutable FusionElementwiseActivationParam param_;
 };
 
 class SoftmaxOp : public OpLite {

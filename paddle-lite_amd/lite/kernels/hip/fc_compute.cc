@@ -42,6 +42,9 @@ class FcCompute : public KernelLite<TARGET(kHIP), Ptype> {
     CHECK(param.activation_type.empty() || param.activation_type == "relu")
         << "fc: only relu can be fused (fc_compute.cc:229-)";
     relu_ = param.activation_type == "relu";
+    // check_fc_use_gemm (fc_compute.cc:66-81): m > 1 and one weight scale -> gemm_s8, whose fp32 output gets its bias
+    // from fill_bias_fc with a second rounding; otherwise gemv_int8 per row with one fused multiply-add
+    single_scale_ = param.weight_scale.size() == 1;
     std::vector<float> s(n_);
     for (int j = 0; j < n_; ++j) {
       const float ws = param.weight_scale[param.weight_scale.size() == 1 ? 0 : j];
@@ -86,8 +89,10 @@ class FcCompute : public KernelLite<TARGET(kHIP), Ptype> {
       y = param.output->template mutable_data<float>(TARGET(kHIP));
       kind = PLHIP_OUT_F32;
     }
+    const bool gemm_route = OutType == PRECISION(kFloat) && m_ > 1 && single_scale_;
     HIP_CALL(ctx.ctx(), plhip_fc_int8(ctx.ctx(), m_, k_, n_, param.input->template data<int8_t>(), weights_.raw_data(),
-                                      scale_.data<float>(), has_bias_ ? bias_.data<float>() : nullptr, relu_ ? 1 : 0, y, kind));
+                                      scale_.data<float>(), has_bias_ ? bias_.data<float>() : nullptr,
+                                      (relu_ ? 1 : 0) | (gemm_route ? 2 : 0), y, kind));
   }
   // the library picks the MFMA kernel when k % 32 == 0 (csrc/misc_ops.hip launch_fc), the dot4 kernels otherwise
   std::string kernel_func_name() const override { return (k_ % 32 == 0) ? "fc_int8_mfma32x32x32_hip" : "fc_int8_dot4_hip"; }
@@ -95,7 +100,7 @@ class FcCompute : public KernelLite<TARGET(kHIP), Ptype> {
  private:
   DDim last_shape_;
   int m_{0}, k_{0}, n_{0};
-  bool relu_{false}, has_bias_{false};
+  bool relu_{false}, has_bias_{false}, single_scale_{false};
   Tensor weights_, scale_, bias_;
 };
 

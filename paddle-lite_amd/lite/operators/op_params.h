@@ -1,7 +1,8 @@
 // op_params.h — the parameter structs the hot-path kernels receive, field-for-field compatible (names, types,
 // defaults) with the subset of lite/operators/op_params.h the ARM int8 kernels read:
 //   WITH_INT8_CONFIG :49-54, IoCopyParam :70, CalibParam :82, FcParam :115-143, SoftmaxParam :319,
-//   ActivationParam :395-419, ConvParam :446-502, PoolParam :539-.
+//   ActivationParam :395-419, ConvParam :446-502, PoolParam :539-, ElementwiseParam :643-651,
+//   FusionElementwiseActivationParam :678-680.
 // Tensors are NOT owned: params hold raw lite::Tensor* into the caller's scope (conv_op.h:72-74); bias may be null;
 // paddings / dilations are shared_ptrs the op may mutate (UpdatePaddingAndDilation, conv_op.cc:55-81).
 #pragma once
@@ -102,6 +103,20 @@ struct PoolParam : ParamBase {
   bool use_quantizer{false};
   std::string data_format{"AnyLayout"};
   WITH_INT8_CONFIG
+};
+
+struct ElementwiseParam : ParamBase {
+  const lite::Tensor* X{};
+  const lite::Tensor* Y{};
+  lite::Tensor* Out{};
+  int axis{-1};  // for broadcasting.
+  WITH_INT8_CONFIG
+  float x_input_scale{1.0};
+  float y_input_scale{1.0};
+};
+
+struct FusionElementwiseActivationParam : public ElementwiseParam {
+  std::string act_type;
 };
 
 }  // namespace operators

@@ -41,6 +41,19 @@ def load():
     L.pllite_add_fc.argtypes = [vp, cs, cs, vp, i32, i32, vp, f32, vp, i32, f32, i32, i32]
     L.pllite_add_global_avg_pool.argtypes = [vp, cs, cs]
     L.pllite_add_softmax.argtypes = [vp, cs, cs]
+    L.pllite_add_pool.argtypes = [vp, cs, cs, cs, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, i32]
+    L.pllite_add_elementwise_add.argtypes = [vp, cs, cs, cs, cs]
+    L.pllite_predictor_create_planner.restype = vp
+    L.pllite_graph_feed.argtypes = [vp, cs, C.POINTER(i64), i32, i32]
+    L.pllite_graph_conv.argtypes = [vp, cs, cs, cs, vp, C.POINTER(i64), vp, C.POINTER(i32), C.POINTER(i32), i32,
+                                    C.POINTER(i32), i32, i32, f32, f32, vp, i32, cs]
+    L.pllite_graph_fc.argtypes = [vp, cs, cs, vp, i32, i32, vp, f32, vp, i32, i32]
+    L.pllite_graph_pool.argtypes = [vp, cs, cs, cs, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, i32]
+    L.pllite_graph_elementwise_add.argtypes = [vp, cs, cs, cs, cs]
+    L.pllite_graph_softmax.argtypes = [vp, cs, cs]
+    L.pllite_graph_fetch.argtypes = [vp, cs]
+    L.pllite_graph_plan.argtypes = [vp, cs, i32]
+    L.pllite_graph_lower.argtypes = [vp, cs, i32]
     L.pllite_set_input.argtypes = [vp, cs, vp, i64]
     L.pllite_run.argtypes = [vp, i32]
     L.pllite_sync.argtypes = [vp]
@@ -62,11 +75,16 @@ def _ia(vals, t=C.c_int):
 class Predictor:
     """Mini CxxPredictor on TARGET(kHIP) (lite/api/hip_predictor.h)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, planner=False):
+        """planner=True: an object that can only build and plan a graph (no device touched) — CPU tests of the
+        lowering rules."""
         self.L = load()
-        if stream is not None:
-            self._ck(self.L.pllite_adopt_stream(device, C.c_void_p(stream)))
-        self.h = self.L.pllite_predictor_create(device)
+        if planner:
+            self.h = self.L.pllite_predictor_create_planner()
+        else:
+            if stream is not None:
+                self._ck(self.L.pllite_adopt_stream(device, C.c_void_p(stream)))
+            self.h = self.L.pllite_predictor_create(device)
         if not self.h:
             raise LiteError("pllite_predictor_create: " + self.L.pllite_last_error().decode())
         self._keep = []
@@ -118,6 +136,65 @@ class Predictor:
 
     def add_softmax(self, src, dst):
         self._ck(self.L.pllite_add_softmax(self.h, src.encode(), dst.encode()))
+
+    def add_pool(self, src, dst, pooling_type, ksize, strides, paddings, global_pooling=False, exclusive=True,
+                 ceil_mode=False):
+        self._ck(self.L.pllite_add_pool(self.h, src.encode(), dst.encode(), pooling_type.encode(), _ia(ksize), _ia(strides),
+                                        _ia(paddings), int(global_pooling), int(exclusive), int(ceil_mode)))
+
+    def add_elementwise_add(self, x, y, dst, act_type=""):
+        self._ck(self.L.pllite_add_elementwise_add(self.h, x.encode(), y.encode(), dst.encode(), act_type.encode()))
+
+    # ---- graph mode: ops as the optimiser sees them; graph_lower() applies the reference's kernel-pick / cast rules
+    def graph_feed(self, name, dims, precision=PREC_FLOAT):
+        self._ck(self.L.pllite_graph_feed(self.h, name.encode(), _ia(dims, C.c_int64), len(dims), precision))
+
+    def graph_conv(self, op_type, src, dst, w, bias, strides, paddings, dilations, groups, act, act_coef, input_scale,
+                   weight_scale, padding_algorithm=""):
+        w = np.ascontiguousarray(w, np.int8)
+        ws = np.ascontiguousarray(weight_scale, np.float32)
+        bp = None
+        if bias is not None:
+            bias = np.ascontiguousarray(bias, np.float32)
+            bp = bias.ctypes.data_as(C.c_void_p)
+        self._ck(self.L.pllite_graph_conv(self.h, op_type.encode(), src.encode(), dst.encode(), w.ctypes.data_as(C.c_void_p),
+                                          _ia(w.shape, C.c_int64), bp, _ia(strides), _ia(paddings), len(paddings),
+                                          _ia(dilations), groups, act, act_coef, input_scale, ws.ctypes.data_as(C.c_void_p),
+                                          ws.size, padding_algorithm.encode()))
+
+    def graph_fc(self, src, dst, w, bias, input_scale, weight_scale, relu=False):
+        w = np.ascontiguousarray(w, np.int8)
+        ws = np.ascontiguousarray(weight_scale, np.float32)
+        bp = None
+        if bias is not None:
+            bias = np.ascontiguousarray(bias, np.float32)
+            bp = bias.ctypes.data_as(C.c_void_p)
+        self._ck(self.L.pllite_graph_fc(self.h, src.encode(), dst.encode(), w.ctypes.data_as(C.c_void_p), w.shape[0],
+                                        w.shape[1], bp, input_scale, ws.ctypes.data_as(C.c_void_p), ws.size, int(relu)))
+
+    def graph_pool(self, src, dst, pooling_type, ksize, strides, paddings, global_pooling=False, exclusive=True,
+                   ceil_mode=False):
+        self._ck(self.L.pllite_graph_pool(self.h, src.encode(), dst.encode(), pooling_type.encode(), _ia(ksize),
+                                          _ia(strides), _ia(paddings), int(global_pooling), int(exclusive), int(ceil_mode)))
+
+    def graph_elementwise_add(self, x, y, dst, act_type=""):
+        self._ck(self.L.pllite_graph_elementwise_add(self.h, x.encode(), y.encode(), dst.encode(), act_type.encode()))
+
+    def graph_softmax(self, src, dst):
+        self._ck(self.L.pllite_graph_softmax(self.h, src.encode(), dst.encode()))
+
+    def graph_fetch(self, name):
+        self._ck(self.L.pllite_graph_fetch(self.h, name.encode()))
+
+    def graph_plan(self):
+        buf = C.create_string_buffer(1 << 18)
+        self._ck(self.L.pllite_graph_plan(self.h, buf, len(buf)))
+        return [s for s in buf.value.decode().split("\n") if s]
+
+    def graph_lower(self):
+        buf = C.create_string_buffer(1 << 14)
+        self._ck(self.L.pllite_graph_lower(self.h, buf, len(buf)))
+        return [s for s in buf.value.decode().split("\n") if s]
 
     def set_input(self, name, arr):
         arr = np.ascontiguousarray(arr)

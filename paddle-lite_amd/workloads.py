@@ -94,3 +94,199 @@ def build_mobilenet_v1(pred, W, batch, res=224):
     pred.add_softmax("logits", "prob")
     pred.add_io_copy("prob", "prob_host", False)
     return "prob_host"
+
+
+# =====================================================================================================================
+# Generic op-list networks ("as the optimiser sees them after its fusion passes") for graph mode
+# (lite/api/graph_builder.h): ResNet50 and MobileNetV2 of BASELINE.json configs C4 / C5, MobileNetV1 again in this form.
+# Layer shapes: lite/tests/benchmark/src/convolution_configs.h:839-891 (ResNet50: stride 2 sits on the 3x3 conv of a
+# stage's first block, shortcut = 1x1 stride-2 conv) and :381-466 (MobileNetV2, t/c/n/s table); PH/PW there are totals.
+# An op is a dict:
+#   conv2d / depthwise_conv2d: name=out, src, w [cout, cin/g, k, k] int8, bias, stride, pad, groups, act (0 none, 1 relu,
+#                              2 relu6), act_coef, in_scale (the activation scale of its input tensor), w_scale [cout]
+#   fc: src, w [k, n], bias, in_scale, w_scale [n]
+#   pool2d: src, pooling_type, ksize, stride, pad, global_pooling
+#   add: x, y, act ("" | "relu")      softmax: src
+# On the reference's ARM target pool2d and elementwise_add exist in fp32 only, so the kernel-pick
+# rule gives the convs in front of them the fp32_out kernel and the consumers behind them a calib.
+# =====================================================================================================================
+class _NetGen:
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.ops = []
+        self.act_scale = {}   # tensor -> quantisation scale its int8 consumers use (Input0_scale)
+        self.sig_i8 = {}      # tensor -> rough std of its int8 image (sizes the synthetic weight scales)
+        self.shape = {}       # tensor -> (c, h, w)
+
+    def tensor(self, name, c, h, w, act_scale, sig_i8):
+        self.shape[name] = (c, h, w)
+        self.act_scale[name] = np.float32(act_scale)
+        self.sig_i8[name] = sig_i8
+
+    def conv(self, name, src, cout, k, stride, pad, groups=1, act=1, act_coef=0.0, out_range=4.0, op=None):
+        cin, h, w = self.shape[src]
+        kk = (cin // groups) * k * k
+        wt = self.rng.integers(-127, 128, (cout, cin // groups, k, k)).astype(np.int8)
+        in_scale = self.act_scale[src]
+        out_scale = np.float32(out_range / 127.0)
+        acc_std = np.sqrt(kk) * self.sig_i8[src] * 73.0
+        var = (1.0 + (np.arange(cout) % 7) / 8.0) / 1.375
+        w_scale = (var * 45.0 * float(out_scale) / (acc_std * float(in_scale))).astype(np.float32)
+        bias = (self.rng.uniform(-0.5, 0.5, cout) * 45.0 * float(out_scale)).astype(np.float32)
+        if op is None:
+            op = "depthwise_conv2d" if (groups == cin and groups == cout and groups > 1) else "conv2d"
+        self.ops.append(dict(op=op, name=name, src=src, w=wt, bias=bias, stride=stride, pad=pad, groups=groups, act=act,
+                             act_coef=float(act_coef), in_scale=in_scale, w_scale=w_scale))
+        ho = (h + 2 * pad - k) // stride + 1
+        wo = (w + 2 * pad - k) // stride + 1
+        self.tensor(name, cout, ho, wo, out_scale, 30.0 if act else 45.0)
+        return name
+
+    def pool(self, name, src, pooling_type, k, stride, pad, global_pooling=False):
+        c, h, w = self.shape[src]
+        self.ops.append(dict(op="pool2d", name=name, src=src, pooling_type=pooling_type, ksize=k, stride=stride, pad=pad,
+                             global_pooling=global_pooling))
+        if global_pooling:
+            self.tensor(name, c, 1, 1, np.float32(self.act_scale[src] * 100.0 / 127.0), 40.0)
+        else:
+            self.tensor(name, c, (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1, self.act_scale[src],
+                        self.sig_i8[src] * 1.3)
+        return name
+
+    def add(self, name, x, y, act=""):
+        c, h, w = self.shape[x]
+        self.ops.append(dict(op="add", name=name, x=x, y=y, act=act))
+        # real-valued std of the sum = hypot of the operands' (int8 std x scale); quantise it so that the int8 image
+        # has a std of ~45 before the relu, like every conv output
+        real = float(np.hypot(self.sig_i8[x] * float(self.act_scale[x]), self.sig_i8[y] * float(self.act_scale[y])))
+        self.tensor(name, c, h, w, np.float32(real / (28.0 if act else 45.0)), 42.0 if act else 45.0)
+        return name
+
+    def fc(self, name, src, n):
+        c, h, w = self.shape[src]
+        k = c * h * w
+        wf = self.rng.integers(-127, 128, (k, n)).astype(np.int8)
+        self.ops.append(dict(op="fc", name=name, src=src, w=wf, bias=self.rng.uniform(-1, 1, n).astype(np.float32),
+                             in_scale=self.act_scale[src],
+                             w_scale=((1.0 + (np.arange(n) % 5) / 8.0) / 127.0 / 32.0).astype(np.float32)))
+        self.tensor(name, n, 1, 1, np.float32(1.0), 30.0)
+        return name
+
+    def softmax(self, name, src):
+        self.ops.append(dict(op="softmax", name=name, src=src))
+        self.shape[name] = self.shape[src]
+        return name
+
+
+def _finish(g, res, out):
+    return dict(ops=g.ops, input="image", input_shape=(3, res, res), output=out, shapes=dict(g.shape))
+
+
+def resnet50_net(seed=50, res=224, num_classes=NUM_CLASSES):
+    g = _NetGen(seed)
+    g.tensor("image", 3, res, res, 1.0 / 127, 73.0)
+    x = g.conv("conv1", "image", 64, 7, 2, 3, act=1)
+    x = g.pool("pool1", x, "max", 3, 2, 1)
+    for si, (width, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]):
+        for b in range(blocks):
+            p = "res%d%s" % (si + 2, "abcdef"[b])
+            s = stride if b == 0 else 1
+            y = g.conv(p + "_branch2a", x, width, 1, 1, 0, act=1)
+            y = g.conv(p + "_branch2b", y, width, 3, s, 1, act=1)
+            y = g.conv(p + "_branch2c", y, 4 * width, 1, 1, 0, act=0)
+            sc = g.conv(p + "_branch1", x, 4 * width, 1, s, 0, act=0) if b == 0 else x
+            x = g.add(p, sc, y, act="relu")
+    x = g.pool("pool5", x, "avg", 7, 1, 0, global_pooling=True)
+    x = g.fc("fc", x, num_classes)
+    x = g.softmax("prob", x)
+    return _finish(g, res, x)
+
+
+MBV2_SETTING = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]
+
+
+def mobilenet_v2_net(seed=52, res=224, num_classes=NUM_CLASSES):
+    g = _NetGen(seed)
+    g.tensor("image", 3, res, res, 1.0 / 127, 73.0)
+    R6 = dict(act=2, act_coef=6.0, out_range=8.0)  # relu6 tensors quantised over [-8, 8]: the clip at 6 is visible in int8
+    x = g.conv("conv1", "image", 32, 3, 2, 1, **R6)
+    cin, bi = 32, 0
+    for (t, c, n, s) in MBV2_SETTING:
+        for i in range(n):
+            bi += 1
+            p = "b%d" % bi
+            stride = s if i == 0 else 1
+            y = x
+            if t != 1:
+                y = g.conv(p + "_expand", y, cin * t, 1, 1, 0, **R6)
+            y = g.conv(p + "_dw", y, cin * t, 3, stride, 1, groups=cin * t, **R6)
+            y = g.conv(p + "_project", y, c, 1, 1, 0, act=0)
+            x = g.add(p + "_add", x, y) if (stride == 1 and cin == c) else y
+            cin = c
+    x = g.conv("conv_last", x, 1280, 1, 1, 0, **R6)
+    x = g.pool("pool", x, "avg", g.shape[x][1], 1, 0, global_pooling=True)
+    x = g.fc("fc", x, num_classes)
+    x = g.softmax("prob", x)
+    return _finish(g, res, x)
+
+
+def mobilenet_v1_net(seed=1234, res=224):
+    """MobileNetV1 in op-list form, same weights as make_mobilenet_v1_weights(seed): graph mode must arrive at exactly
+    the Appendix-D program that build_mobilenet_v1 writes out by hand."""
+    W = make_mobilenet_v1_weights(seed, res)
+    ops = []
+    cur = "image"
+    for (name, op, cin, cout, k, s, p, g, hin) in mobilenet_v1_layers(res):
+        L = W[name]
+        ops.append(dict(op=op, name=name, src=cur, w=L["w"], bias=L["bias"], stride=s, pad=p, groups=g, act=1, act_coef=0.0,
+                        in_scale=L["in_scale"], w_scale=L["w_scale"]))
+        cur = name
+    ops.append(dict(op="pool2d", name="pool", src=cur, pooling_type="avg", ksize=7, stride=1, pad=0, global_pooling=True))
+    F = W["fc"]
+    ops.append(dict(op="fc", name="logits", src="pool", w=F["w"], bias=F["bias"], in_scale=F["in_scale"], w_scale=F["w_scale"]))
+    ops.append(dict(op="softmax", name="prob", src="logits"))
+    return dict(ops=ops, input="image", input_shape=(3, res, res), output="prob", shapes={})
+
+
+def net_stats(net):
+    """MACs and algorithmic activation bytes per image by op class (int8 tensors 1 B/elt, fp32 tensors 4 B/elt are
+    decided by the lowering; here: conv MACs and element counts only)."""
+    macs = {"conv1x1": 0, "conv_kxk": 0, "depthwise": 0, "fc": 0}
+    shapes = net["shapes"]
+    for o in net["ops"]:
+        if o["op"] in ("conv2d", "depthwise_conv2d"):
+            cout, cg, k, _ = o["w"].shape
+            c, h, w = shapes[o["name"]]
+            m = h * w * cout * cg * k * k
+            key = "depthwise" if o["op"] == "depthwise_conv2d" else ("conv1x1" if k == 1 else "conv_kxk")
+            macs[key] += m
+        elif o["op"] == "fc":
+            macs["fc"] += o["w"].shape[0] * o["w"].shape[1]
+    return macs
+
+
+def emit_graph(pred, net, batch):
+    """Feed the op list to the predictor's graph mode and lower it.  Returns the host name of the output variable."""
+    from . import liteapi
+    c, h, w = net["input_shape"]
+    pred.graph_feed(net["input"], (batch, c, h, w), liteapi.PREC_FLOAT)
+    for o in net["ops"]:
+        t = o["op"]
+        if t in ("conv2d", "depthwise_conv2d"):
+            p = o["pad"]
+            pred.graph_conv(t, o["src"], o["name"], o["w"], o["bias"], (o["stride"],) * 2, (p, p, p, p), (1, 1), o["groups"],
+                            o["act"], o["act_coef"], float(o["in_scale"]), o["w_scale"])
+        elif t == "fc":
+            pred.graph_fc(o["src"], o["name"], o["w"], o["bias"], float(o["in_scale"]), o["w_scale"], False)
+        elif t == "pool2d":
+            p = o["pad"]
+            pred.graph_pool(o["src"], o["name"], o["pooling_type"], (o["ksize"],) * 2, (o["stride"],) * 2, (p, p, p, p),
+                            o["global_pooling"], True, False)
+        elif t == "add":
+            pred.graph_elementwise_add(o["x"], o["y"], o["name"], o["act"])
+        elif t == "softmax":
+            pred.graph_softmax(o["src"], o["name"])
+        else:
+            raise ValueError(t)
+    pred.graph_fetch(net["output"])
+    return net["output"] + "/host"

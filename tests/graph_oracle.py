@@ -1,0 +1,99 @@
+"""Oracle (CPU) execution of an op-list network (paddle-lite_amd/workloads.py) with the reference's semantics.
+
+TEST INFRASTRUCTURE.  Independent of lite/api/graph_builder.cc: the kernel-pick rule and the cast placement are
+restated here from the reference (static_kernel_pick_pass.cc:92-165: int8 output iff every consumer is enable_int8,
+output scale = first consumer's input scale; type_precision_cast_pass.cc:60-100: one calib per source tensor, scale of
+the first int8 consumer), and every op is computed with oracle/plref (conv / fc / calib restated from the ARM path,
+pool2d from pooling.cc:38-215, elementwise_add{,_relu} from elementwise.cc).
+Returns name -> tensor for every variable of the lowered program ("<var>/precision_trans" for calib outputs)."""
+import numpy as np
+
+INT8_OPS = ("conv2d", "depthwise_conv2d", "fc")
+
+
+def plan(net):
+    """[(kind, dict)] in execution order; kind in {calib, op}."""
+    ops = net["ops"]
+    out_name = lambda o: o["name"]
+    ins = lambda o: [o["x"], o["y"]] if o["op"] == "add" else [o["src"]]
+    consumers = {}
+    for i, o in enumerate(ops):
+        for v in ins(o):
+            consumers.setdefault(v, []).append(i)
+    steps, prec, cast = [], {net["input"]: "f32"}, {}
+    for i, o in enumerate(ops):
+        is8 = o["op"] in INT8_OPS
+        want = "i8" if is8 else "f32"
+        use = []
+        for v in ins(o):
+            if prec[v] != want:
+                if v not in cast:
+                    assert want == "i8", "int8 -> fp32 casts do not occur in these graphs"
+                    cast[v] = v + "/precision_trans"
+                    steps.append(("calib", dict(src=v, dst=cast[v], scale=float(o["in_scale"]))))
+                use.append(cast[v])
+            else:
+                use.append(v)
+        int8_out, oscale = False, 1.0
+        if is8:
+            cs = consumers.get(out_name(o), [])
+            int8_out = bool(cs) and all(ops[c]["op"] in INT8_OPS for c in cs) and out_name(o) != net["output"]
+            if int8_out:
+                oscale = float(ops[cs[0]]["in_scale"])
+        steps.append(("op", dict(o=o, ins=use, int8_out=int8_out, oscale=oscale)))
+        prec[out_name(o)] = "i8" if int8_out else "f32"
+    return steps
+
+
+def forward(plref, net, image, keep=None):
+    """keep: optional set of variable names to retain (None = all)."""
+    T = {net["input"]: np.ascontiguousarray(image, np.float32)}
+    out = {}
+
+    def put(name, val):
+        T[name] = val
+        if keep is None or name in keep:
+            out[name] = val
+
+    for kind, s in plan(net):
+        if kind == "calib":
+            put(s["dst"], plref.calib_f32_to_i8(T[s["src"]], s["scale"]))
+            continue
+        o, ins = s["o"], s["ins"]
+        t = o["op"]
+        if t in ("conv2d", "depthwise_conv2d"):
+            x = T[ins[0]]
+            cout, cg, k, _ = o["w"].shape
+            p = o["pad"]
+            sh = plref.shape(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, k, k, (p, p, p, p),
+                             (o["stride"],) * 2, (1, 1), o["groups"])
+            y, _ = plref.conv2d(sh, x, o["w"], o["bias"], float(o["in_scale"]), o["w_scale"], s["oscale"], o["act"],
+                                o["act_coef"], s["int8_out"])
+            put(o["name"], y)
+        elif t == "fc":
+            x = T[ins[0]]
+            x2 = x.reshape(x.shape[0], -1)
+            if s["int8_out"]:
+                sc = (o["w_scale"] * np.float32(o["in_scale"]) / np.float32(s["oscale"])).astype(np.float32)
+                b = (o["bias"] / np.float32(s["oscale"])).astype(np.float32)
+            else:
+                sc = (o["w_scale"] * np.float32(o["in_scale"])).astype(np.float32)
+                b = o["bias"]
+            y, _ = plref.fc(x2, o["w"], b, sc, False, s["int8_out"], route=plref.fc_route(x2.shape[0], o["w_scale"].size))
+            put(o["name"], y)
+        elif t == "pool2d":
+            x = T[ins[0]]
+            if o["global_pooling"] and o["pooling_type"] == "avg":
+                put(o["name"], plref.global_avg_pool(x))
+            else:
+                p = o["pad"]
+                put(o["name"], plref.pool2d(x, o["pooling_type"], (o["ksize"],) * 2, (o["stride"],) * 2, (p, p, p, p),
+                                            exclusive=True, ceil_mode=False))
+        elif t == "add":
+            put(o["name"], plref.elementwise_add(T[ins[0]], T[ins[1]], o["act"] == "relu"))
+        elif t == "softmax":
+            put(o["name"], plref.softmax(T[ins[0]]))
+        else:
+            raise ValueError(t)
+        # free tensors no later step needs? nets are small at test batch sizes; keep it simple
+    return out

@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def forward(plref, wl, W, image, res=224, upto=None):
+def forward(plref, wl, W, image, res=224, upto=None, via_gemm=False):
     """Returns dict name -> tensor for every variable of the Appendix-D program."""
     out = {}
     x = plref.calib_f32_to_i8(image, float(W["input_scale"]))
@@ -13,7 +13,7 @@ def forward(plref, wl, W, image, res=224, upto=None):
         last = i == len(layers) - 1
         sh = plref.shape(x.shape[0], cin, x.shape[2], x.shape[3], cout, k, k, (p, p, p, p), (s, s), (1, 1), g)
         y, _ = plref.conv2d(sh, x, L["w"], L["bias"], float(L["in_scale"]), L["w_scale"], float(L["out_scale"]), 1, 0.0,
-                            not last)
+                            not last, via_gemm=(via_gemm and g == 1))
         out[name] = y
         x = y
         if upto == name:

@@ -1,0 +1,215 @@
+"""-m gpu: the glue ops and the whole ResNet50-INT8 / MobileNetV2-INT8 programs (BASELINE configs C4 / C5) against the
+oracle graph, every variable of the lowered program; and the MobileNetV1 program (C3) at its own batch, 128."""
+import importlib
+
+import numpy as np
+import pytest
+
+import graph_oracle
+import mbv1_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lite(pkg):
+    return importlib.import_module("paddle_lite_amd.liteapi")
+
+
+@pytest.fixture(scope="module")
+def wl(pkg):
+    return importlib.import_module("paddle_lite_amd.workloads")
+
+
+def test_pool2d_sweep_vs_oracle(gpu_ctx, plref):
+    """pooling_basic semantics (pooling.cc:38-215): max and avg (exclusive and not), pads 0-2 incl. asymmetric,
+    ceil_mode, windows hanging over the edge.  Same operation order on both sides: bit-exact."""
+    rng = np.random.default_rng(300)
+    cases = [  # n, c, h, w, k, s, pads, ceil
+        (2, 64, 112, 112, 3, 2, (1, 1, 1, 1), False),   # ResNet50 pool1
+        (1, 3, 7, 9, 2, 2, (0, 0, 0, 0), False), (2, 5, 15, 15, 3, 1, (1, 1, 1, 1), False),
+        (1, 4, 8, 8, 3, 2, (0, 0, 0, 0), True), (1, 2, 14, 14, 2, 2, (1, 1, 1, 1), False),
+        (1, 3, 13, 17, 3, 2, (0, 1, 1, 2), False), (3, 7, 5, 5, 5, 1, (2, 2, 2, 2), False),
+        (1, 1, 6, 6, 3, 3, (1, 1, 1, 1), True), (1, 2, 33, 3, 3, 2, (1, 1, 1, 1), False),
+    ]
+    for (n, c, h, w, k, s, pads, ceil) in cases:
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        for typ, excl in (("max", True), ("avg", True), ("avg", False)):
+            got = gpu_ctx.pool2d(x, typ, (k, k), (s, s), pads, exclusive=excl, ceil_mode=ceil)
+            ref = plref.pool2d(x, typ, (k, k), (s, s), pads, exclusive=excl, ceil_mode=ceil)
+            assert got.shape == ref.shape
+            assert np.array_equal(got, ref), (h, w, k, s, pads, typ, excl)
+
+
+def test_elementwise_add_vs_oracle(gpu_ctx, plref):
+    rng = np.random.default_rng(301)
+    for shape in [(2, 256, 56, 56), (1, 3, 5, 7), (1, 1, 1, 1), (3, 24, 17, 17)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        y = rng.standard_normal(shape).astype(np.float32)
+        for relu in (False, True):
+            assert np.array_equal(gpu_ctx.elementwise_add(x, y, relu), plref.elementwise_add(x, y, relu))
+
+
+def test_fc_both_reference_routes(gpu_ctx, plref, pkg):
+    """fp32-out fc: bit 1 of the flag word selects gemm_s8 + fill_bias_fc's two roundings (fc_compute.cc:250-266);
+    both routes bit-exact against their oracle restatements, for the MFMA (k % 32 == 0) and the dot4 kernels."""
+    capi = pkg.capi
+    rng = np.random.default_rng(302)
+    for (m, k, n) in [(9, 256, 513), (4, 100, 37), (33, 1024, 1000)]:
+        x = rng.integers(-127, 128, (m, k)).astype(np.int8)
+        w = rng.integers(-127, 128, (k, n)).astype(np.int8)
+        bias = rng.uniform(-1, 1, n).astype(np.float32)
+        sc = np.full(n, 1.7 / 127 / 127, np.float32)
+        for relu in (0, 1):
+            y0, _ = plref.fc(x, w, bias, sc, relu, False, route=0)
+            y1, _ = plref.fc(x, w, bias, sc, relu, False, route=1)
+            assert np.array_equal(gpu_ctx.fc(x, w, sc, bias, relu, capi.OUT_F32), y0)
+            assert np.array_equal(gpu_ctx.fc(x, w, sc, bias, relu | 2, capi.OUT_F32), y1)
+
+
+def test_fc_kernel_classes_pick_the_reference_route(lite, plref):
+    """FcCompute<kInt8,kFloat> with a single weight scale and m > 1 takes the gemm_s8 route, with per-column scales
+    the gemv route (check_fc_use_gemm, fc_compute.cc:66-81); FcCompute<kInt8,kInt8> (alias int8out) driven through
+    the kernel class."""
+    rng = np.random.default_rng(303)
+    m, k, n = 6, 128, 70
+    x = rng.integers(-127, 128, (m, k)).astype(np.int8)
+    w = rng.integers(-127, 128, (k, n)).astype(np.int8)
+    bias = rng.uniform(-1, 1, n).astype(np.float32)
+    for ws, int8_out in [(np.array([0.9 / 127], np.float32), False), (((1 + np.arange(n) % 5) / 127.0 / 4).astype(np.float32), False),
+                         (np.array([0.9 / 127], np.float32), True), (((1 + np.arange(n) % 5) / 127.0 / 4).astype(np.float32), True)]:
+        in_scale, out_scale = 1 / 127.0, 0.05
+        p = lite.Predictor(0)
+        try:
+            p.add_feed("x", x.shape, lite.PREC_INT8)
+            p.add_io_copy("x", "xd", True)
+            p.add_fc("xd", "yd", w, bias, in_scale, ws, out_scale, int8_out, True)
+            p.add_io_copy("yd", "y", False)
+            p.set_input("x", x)
+            p.run()
+            y = p.get_var("y", np.int8 if int8_out else np.float32)
+            names = p.kernel_names()
+        finally:
+            p.close()
+        wsn = np.resize(ws, n).astype(np.float32)
+        if int8_out:
+            sc = (wsn * np.float32(in_scale) / np.float32(out_scale)).astype(np.float32)
+            ref, _ = plref.fc(x, w, (bias / np.float32(out_scale)).astype(np.float32), sc, True, True)
+            assert any("fc:hip/int8_t" in s_ or "int8out" in s_ for s_ in names)
+        else:
+            sc = (wsn * np.float32(in_scale)).astype(np.float32)
+            ref, _ = plref.fc(x, w, bias, sc, True, False, route=plref.fc_route(m, ws.size))
+        assert np.array_equal(y, ref), (ws.size, int8_out)
+
+
+def _run_graph(lite, wl, net, img):
+    p = lite.Predictor(0)
+    try:
+        out = wl.emit_graph(p, net, img.shape[0])
+        fetched = p.graph_lower()
+        assert fetched == [out]
+        p.set_input(net["input"], img)
+        p.run()
+        p.run(skip_io_copy=False)  # second launch: ReInitWhenNeeded no-op paths
+        return p, out
+    except Exception:
+        p.close()
+        raise
+
+
+def _compare_all(p, ref, net):
+    n_i8 = n_f32 = 0
+    for name, want in ref.items():
+        dev_name = name
+        got = p.get_var(dev_name, want.dtype)
+        assert got.shape == want.shape, name
+        if want.dtype == np.int8:
+            assert np.array_equal(got, want), "%s: %d of %d int8 values differ" % (name, (got != want).sum(), want.size)
+            n_i8 += 1
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=name)
+            n_f32 += 1
+    return n_i8, n_f32
+
+
+def test_resnet50_int8_program_vs_oracle_graph(lite, wl, plref):
+    """BASELINE config C4's graph (53 convs, max pool, 16 residual adds with fused relu, avg pool, fc, softmax) at
+    batch 2, 224x224: every int8 tensor of the lowered program bit-exact, fp32 tensors within 1e-5."""
+    net = wl.resnet50_net()
+    img = np.random.default_rng(310).uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+    ref = graph_oracle.forward(plref, net, img)
+    p, out = _run_graph(lite, wl, net, img)
+    try:
+        names = p.kernel_names()
+        assert sum(n.startswith("conv2d") for n in names) == 53
+        assert sum("fusion_elementwise_add_activation" in n for n in names) == 16
+        assert sum(n.startswith("calib") for n in names) == 18 and sum(n.startswith("pool2d") for n in names) == 2
+        n_i8, n_f32 = _compare_all(p, ref, net)
+        assert n_i8 == 18 + 32 and n_f32 >= 21 + 16 + 2
+        prob = p.get_var(out, np.float32)
+        np.testing.assert_allclose(prob, ref["prob"], rtol=1e-4, atol=1e-7)
+        for name in ["res2a/precision_trans", "res3d_branch2b", "res5c_branch2a"]:
+            got = p.get_var(name, np.int8)
+            assert 0.02 < (got != 0).mean() and (np.abs(got.astype(np.int32)) == 127).mean() < 0.2, name
+    finally:
+        p.close()
+
+
+def test_mobilenet_v2_int8_program_vs_oracle_graph(lite, wl, plref):
+    """BASELINE config C5's graph (relu6 epilogues, linear bottlenecks, 10 residual adds) at batch 3, 224x224."""
+    net = wl.mobilenet_v2_net()
+    img = np.random.default_rng(311).uniform(-1, 1, (3, 3, 224, 224)).astype(np.float32)
+    ref = graph_oracle.forward(plref, net, img)
+    p, out = _run_graph(lite, wl, net, img)
+    try:
+        names = p.kernel_names()
+        assert sum(n.startswith("depthwise_conv2d") for n in names) == 17
+        assert sum(n.startswith("conv2d") for n in names) == 35
+        assert sum(n.startswith("elementwise_add") for n in names) == 10
+        _compare_all(p, ref, net)
+        # the relu6 clip is visible in int8: 6 / (8/127) = 95
+        e = p.get_var("b2_expand", np.int8)
+        assert e.max() == 95 and (e == 95).mean() > 1e-4
+        np.testing.assert_allclose(p.get_var(out, np.float32), ref["prob"], rtol=1e-4, atol=1e-7)
+    finally:
+        p.close()
+
+
+def test_mobilenet_v1_int8_program_at_batch_128(lite, wl, plref):
+    """C3 at its own batch: grid sizes, XCD tile maps and the 2-blocks-per-CU regime of the benchmark run, compared with
+    the oracle graph (im2col + GEMM form of the oracle for speed: same accumulators bit for bit, tests/test_oracle.py)."""
+    B = 128
+    W = wl.make_mobilenet_v1_weights(seed=1234)
+    img = np.random.default_rng(312).uniform(-1, 1, (B, 3, 224, 224)).astype(np.float32)
+    ref = mbv1_oracle.forward(plref, wl, W, img, via_gemm=True)
+    p = lite.Predictor(0)
+    try:
+        out = wl.build_mobilenet_v1(p, W, B)
+        p.set_input("image", img)
+        p.run()
+        for name, want in ref.items():
+            if want.dtype != np.int8:
+                continue
+            got = p.get_var(name, np.int8)
+            assert np.array_equal(got, want), "%s: %d of %d differ" % (name, (got != want).sum(), want.size)
+        np.testing.assert_allclose(p.get_var("pw14", np.float32), ref["pw14"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(p.get_var("logits", np.float32), ref["logits"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(p.get_var(out, np.float32), ref["prob"], rtol=1e-4, atol=1e-7)
+    finally:
+        p.close()
+
+
+def test_pointwise_7x7_rows_at_the_end_of_an_allocation(gpu_ctx, plref, pkg):
+    """HW = 49 rows are not a multiple of 4 bytes: the ring kernel's END-aligned 16-byte pieces must use the true row
+    length (round 1 passed the length rounded up to 4 and read 3 bytes past the last row).  pw13's shape at batch 128:
+    the input is exactly 784 pages and Context.to_device allocates exactly its size, so it ends where the allocation ends."""
+    capi = pkg.capi
+    rng = np.random.default_rng(320)
+    n, cin, cout = 128, 512, 1024
+    x = rng.integers(-127, 128, (n, cin, 7, 7)).astype(np.int8)
+    assert x.nbytes % 4096 == 0
+    w = rng.integers(-127, 128, (cout, cin, 1, 1)).astype(np.int8)
+    d = capi.conv_desc(n, cin, 7, 7, cout, 1, 1)
+    acc = gpu_ctx.conv2d(d, x, w, None, None, capi.OUT_I32)
+    s = plref.shape(n, cin, 7, 7, cout, 1, 1, (0, 0, 0, 0), (1, 1), (1, 1), 1)
+    assert np.array_equal(acc, plref.conv2d_acc(s, x, w, via_gemm=True))

@@ -1,0 +1,123 @@
+"""Host logic of graph mode (lite/api/graph_builder.*): kernel pick and cast placement, checked on the CPU (no device)
+against the hand-written Appendix-D program and against tests/graph_oracle.py's independent restatement of the same
+reference passes; plus the oracle's new glue ops against torch's CPU ops (independent cross-check)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import graph_oracle
+
+
+@pytest.fixture(scope="module")
+def lite(pkg):
+    return importlib.import_module("paddle_lite_amd.liteapi")
+
+
+@pytest.fixture(scope="module")
+def wl(pkg):
+    return importlib.import_module("paddle_lite_amd.workloads")
+
+
+def _plan(lite, wl, net, batch=2):
+    p = lite.Predictor(planner=True)
+    try:
+        wl.emit_graph(p, net, batch)
+        return p.graph_plan()
+    finally:
+        p.close()
+
+
+def test_mobilenet_v1_graph_mode_arrives_at_appendix_d(lite, wl):
+    plan = _plan(lite, wl, wl.mobilenet_v1_net())
+    kinds = [l.split(" ")[0] for l in plan]
+    expect = ["io_copy/host_to_device", "calib/fp32_to_int8", "conv2d/int8_out"]
+    for i in range(13):
+        expect += ["depthwise_conv2d/int8_out", "conv2d/int8_out" if i < 12 else "conv2d/fp32_out"]
+    expect += ["pool2d/def", "calib/fp32_to_int8", "fc/fp32out", "softmax/def", "io_copy/device_to_host"]
+    assert kinds == expect
+    W = wl.make_mobilenet_v1_weights(1234)
+    # output scale of an int8_out conv = the input scale of its consumer (static_kernel_pick_pass.cc:118-121)
+    assert "oscale=%.9g" % float(W["dw2"]["in_scale"]) in plan[2]
+    assert "scale=%.9g" % float(W["input_scale"]) in plan[1]
+    assert "scale=%.9g" % float(W["pool_scale"]) in plan[-4]
+
+
+@pytest.mark.parametrize("which", ["resnet50", "mobilenet_v2"])
+def test_plan_matches_independent_restatement(lite, wl, which):
+    net = wl.resnet50_net(res=64) if which == "resnet50" else wl.mobilenet_v2_net(res=64)
+    plan = _plan(lite, wl, net)
+    ref = graph_oracle.plan(net)
+    body = plan[1:-1]  # io_copy at both ends
+    assert plan[0].startswith("io_copy/host_to_device") and plan[-1].startswith("io_copy/device_to_host")
+    assert len(body) == len(ref)
+    n_fp32_convs = n_calib = 0
+    for line, (kind, s) in zip(body, ref):
+        if kind == "calib":
+            n_calib += 1
+            assert line.startswith("calib/fp32_to_int8"), line
+            assert " out=%s " % s["dst"] in line and "scale=%.9g" % s["scale"] in line, (line, s)
+        else:
+            o = s["o"]
+            assert " out=%s" % o["name"] in line, (line, o["name"])
+            if o["op"] in graph_oracle.INT8_OPS:
+                alias = ("int8out" if s["int8_out"] else "fp32out") if o["op"] == "fc" else ("int8_out" if s["int8_out"] else "fp32_out")
+                assert line.startswith(o["op"] + "/" + alias), (line, alias)
+                n_fp32_convs += not s["int8_out"]
+                if s["int8_out"]:
+                    assert "oscale=%.9g" % s["oscale"] in line
+                ins = line.split(" in=")[1].split(" ")[0].split(",")
+                assert [i.replace("/target_trans", "") for i in ins] == s["ins"]
+    if which == "resnet50":
+        # conv1 (-> max pool), 16 x branch2c and 4 x branch1 (-> add), fc; one calib per residual-stream tensor:
+        # image, pool1, 16 block outputs (the last feeds pool5 only), pool5
+        assert n_fp32_convs == 1 + 16 + 4 + 1 and n_calib == 1 + 1 + 15 + 1
+    else:
+        # projects that feed an add (10), projects whose output is the next block's expand input AND its add operand
+        # (b2, b4, b7, b11, b14), conv_last (-> pool), fc
+        assert n_fp32_convs == 10 + 5 + 1 + 1
+
+
+def test_oracle_pool2d_against_torch(plref):
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    rng = np.random.default_rng(5)
+    for (h, w, k, s, p) in [(112, 112, 3, 2, 1), (7, 9, 2, 2, 0), (15, 15, 3, 1, 1), (8, 8, 3, 2, 0), (14, 14, 2, 2, 1)]:
+        x = rng.standard_normal((2, 3, h, w)).astype(np.float32)
+        got = plref.pool2d(x, "max", (k, k), (s, s), (p, p, p, p))
+        ref = F.max_pool2d(torch.from_numpy(x), k, s, p).numpy()
+        assert np.array_equal(got, ref), (h, k, s, p)
+        got = plref.pool2d(x, "avg", (k, k), (s, s), (p, p, p, p), exclusive=True)
+        ref = F.avg_pool2d(torch.from_numpy(x), k, s, p, count_include_pad=False).numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-6)
+    # windows of the reference's graphs: ResNet50's 3x3 s2 p1 max pool halves 112 -> 56
+    assert plref.pool2d(np.zeros((1, 1, 112, 112), np.float32), "max", (3, 3), (2, 2), (1, 1, 1, 1)).shape[2:] == (56, 56)
+
+
+def test_oracle_elementwise_add(plref):
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2, 5, 7, 3)).astype(np.float32)
+    y = rng.standard_normal((2, 5, 7, 3)).astype(np.float32)
+    assert np.array_equal(plref.elementwise_add(x, y), x + y)
+    assert np.array_equal(plref.elementwise_add(x, y, True), np.maximum(x + y, 0))
+
+
+def test_fc_routes_differ_by_at_most_one_ulp(plref):
+    """gemm_s8 + fill_bias_fc rounds twice, gemv_int8's vmlaq once.  The extra rounding is the
+    product's: the two results are at most half an ulp of the product plus one ulp of the result apart — and really
+    different somewhere (otherwise the route switch would be untested)."""
+    rng = np.random.default_rng(7)
+    m, k, n = 9, 256, 513
+    x = rng.integers(-127, 128, (m, k)).astype(np.int8)
+    w = rng.integers(-127, 128, (k, n)).astype(np.int8)
+    bias = rng.uniform(-1, 1, n).astype(np.float32)
+    sc = np.full(n, 1.7 / 127 / 127, np.float32)
+    y0, acc = plref.fc(x, w, bias, sc, False, False, route=0)
+    y1, _ = plref.fc(x, w, bias, sc, False, False, route=1)
+    prod = acc.astype(np.float32) * sc
+    bound = 0.5 * np.spacing(np.abs(prod)) + np.spacing(np.maximum(np.abs(y0), np.abs(y1)))
+    assert np.all(np.abs(y0.astype(np.float64) - y1) <= bound)
+    assert np.any(y0 != y1)
+    # route 1 is exactly "product rounded, then sum rounded"
+    assert np.array_equal(y1, (acc.astype(np.float32) * sc) + bias)
+    assert plref.fc_route(1, 1) == 0 and plref.fc_route(4, 1) == 1 and plref.fc_route(4, n) == 0
