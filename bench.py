@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — INT8 images/sec of the MobileNetV1 224x224 graph on N MI355X GPUs (BASELINE.json metric).
+"""bench.py — INT8 images/sec of the BASELINE.json graphs on N MI355X GPUs.
 
-A step = one pass of the hot path (calib -> 27 int8 convs -> pool -> calib -> fc -> softmax, the program of
-SURVEY.md Appendix D) over one synthetic batch (128 images) per GPU, through the C++ kHIP kernel classes and libplhip.so.
-By default 3 predictors per GPU (one host thread + HIP stream each) run whole batches, the timed K steps being dealt
-round-robin, so three steps are in flight at once and fill each other's dispatch gaps, launch ramps and tails
-(`--inflight 1`: strictly serial; the serial rate is also reported as `single_stream`).
-Inputs are resident in HBM when the timed region starts (the host->device io_copy instruction is skipped).
-N > 1: one process per GPU (torch.distributed, backend "nccl" == RCCL): rank 0's weights are broadcast over xGMI
-at init, every rank runs its own batch shard (no collective inside the layer loop) and the logits are all-gathered
-each step.  Weak scaling: the per-GPU batch is fixed.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4|c5|c2] [--scaling weak|strong]
+                    [--batch B | --global-batch B] [--inflight P]
 
-The JSON line carries `roofline` for the dominant kernel family (time measured live with HIP events on the launch
-stream, one event pair per launch) and `cpu_baseline` (the oracle's im2col+GEMM port of the reference algorithm,
-OpenMP on the host cores, bounded sample; rank 0, N = 1 only).
+Default (what the driver runs): config C3 = MobileNetV1-INT8 full graph, batch 128 per GPU (BASELINE.json metric).
+  c4 = ResNet50-INT8 batch 256, c5 = MobileNetV2-INT8 global batch 1024 split over the GPUs (strong scaling),
+  c2 = the single conv2d_int8 op (N=32 Cin=64 Cout=128 56x56 k3 s1), N = 1 only.
+A step = one pass of the lowered program (calib -> int8 convs [+ fp32 pool / residual adds] -> pool -> calib -> fc ->
+softmax) over one synthetic batch, through the C++ kHIP kernel classes and libplhip.so.  By
+default 3 predictors per GPU (one host thread + HIP stream each, the reference's predictor-per-thread serving model)
+run whole steps, dealt round-robin, so three steps are in flight and fill each other's dispatch gaps (`--inflight 1`:
+strictly serial; also reported as `single_stream`).  Inputs are resident in HBM when the timed region starts.
+
+N > 1: one process per GPU (torch.distributed "nccl" == RCCL over xGMI).  `--gpus N` without a launcher environment
+makes this script start its own N rank processes (fresh children, before anything touches the GPU); under
+`torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE.  Rank 0 builds the network and broadcasts it, generates
+ONE global batch and scatters the shards (sharding.shard_range); every step each rank runs its shard (no collective in
+the layer loop) and the [rows, 1000] probabilities are all-gathered asynchronously, overlapping the next steps.
+weak: global batch = --batch x N; strong: global batch fixed (--global-batch).
+
+The JSON line carries `roofline` for the dominant kernel family (launch time measured live with HIP events on the launch
+stream) and `cpu_baseline` (oracle port of the reference algorithm on the host cores, bounded sample; rank 0, N = 1).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,158 +39,312 @@ sys.path.insert(0, ROOT)
 # 2x the bf16 rate = 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz = 5.03 POP/s (sparsity figures not used).
 HBM_PEAK_GBS = 8000.0
 MFMA_I8_PEAK_TOPS = 256 * 4 * 2048 * 2.4e9 / 1e12
+BALANCE_OPS_PER_BYTE = MFMA_I8_PEAK_TOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+CONFIGS = {
+    "c3": dict(model="mobilenet_v1", batch=128, title="MobileNetV1 INT8 full graph 224x224 (27 int8 convs + pool + fc + softmax)",
+               metric="INT8 images/sec MobileNetV1 224x224"),
+    "c4": dict(model="resnet50", batch=256, title="ResNet50 INT8 full graph 224x224 (53 int8 convs, max pool, 16 residual adds)",
+               metric="INT8 images/sec ResNet50 224x224"),
+    "c5": dict(model="mobilenet_v2", batch=128, global_batch=1024, scaling="strong",
+               title="MobileNetV2 INT8 full graph 224x224 (52 int8 convs, relu6, 10 residual adds)",
+               metric="INT8 images/sec MobileNetV2 224x224"),
+    "c2": dict(model="conv", batch=32, title="single conv2d_int8 op N=32 Cin=64 Cout=128 HW=56 k=3 s=1 p=1, int8 out",
+               metric="INT8 images/sec conv2d 64->128 3x3 56x56"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)   # ~0.13 s timed at 0.42 ms / step: steadier than a 20 ms window
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE config: batch=128 on 1 GPU)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU and step (weak scaling); default: the config's")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
+    ap.add_argument("--global-batch", type=int, default=None, help="strong scaling: images per step over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--layer-table", action="store_true", help="print the per-layer timing table to stderr")
+    ap.add_argument("--layer-table", action="store_true", help="print the per-instruction timing table to stderr")
     ap.add_argument("--inflight", type=int, default=3,
-                    help="predictors per GPU, each on its own host thread + HIP stream, each running WHOLE batches of "
-                         "--batch images; the steps are dealt round-robin, so --inflight steps are in flight at once "
-                         "(the reference's one-predictor-per-thread serving model, cxx_api.h:103-137). Kernels of "
-                         "different steps overlap: dispatch gaps, launch ramps and tails of one step are filled by the "
-                         "others. 1 = strictly serial steps.")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="predictors per GPU, each on its own host thread + HIP stream with batch/streams images "
-                         "(the reference's one-predictor-per-thread model, cxx_api.h:103-137); kernels of different "
-                         "streams overlap, hiding per-launch fill/drain")
-    return ap.parse_args()
+                    help="predictors per GPU, each on its own host thread + HIP stream, each running WHOLE steps; the steps "
+                         "are dealt round-robin, so --inflight steps are in flight at once (the reference's "
+                         "one-predictor-per-thread serving model, cxx_api.h:103-137). 1 = strictly serial steps.")
+    ap.add_argument("--res", type=int, default=224, help=argparse.SUPPRESS)  # tests only
+    return ap.parse_args(argv)
 
 
-def layer_costs(wl, batch):
-    """Algorithmic ops / bytes per instruction family for one step (unique in + weights + out once)."""
-    fam = {}
-    for (name, op, cin, cout, k, s, p, g, hin) in wl.mobilenet_v1_layers():
-        ho = (hin + 2 * p - k) // s + 1
-        macs = batch * ho * ho * cout * (cin // g) * k * k
-        out_b = 4 if name == "pw14" else 1
-        byts = batch * (cin * hin * hin + cout * ho * ho * out_b) + cout * (cin // g) * k * k
-        key = "conv3x3s2_first" if name == "conv1" else ("depthwise3x3" if g > 1 else "pointwise1x1")
-        fam.setdefault(key, {"ops": 0, "bytes": 0, "names": []})
-        fam[key]["ops"] += 2 * macs
-        fam[key]["bytes"] += byts
-        fam[key]["names"].append(name)
-    return fam
+# =====================================================================================================================
+# self-launch: `bench.py --gpus N` without a launcher environment
+# =====================================================================================================================
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def cpu_baseline(wl, W, seconds):
-    """The reference algorithm restated for the host (oracle/plref.c): im2col + int8 GEMM over (batch, group) for the
-    dense convs (conv_impl.cc:490-598 structure), direct loops for depthwise, fused float epilogue; OpenMP."""
-    from oracle import plref
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def spawn_ranks(args):
+    """Start N fresh rank processes of this script (nothing in this process has touched the GPU: torch is not even
+    imported yet), relay rank 0's JSON line, fail if any rank failed or fewer than N joined."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rc != 0 for rc in rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        return 1
+    try:
+        line = json.loads([l for l in out0.splitlines() if l.startswith("{")][-1])
+    except Exception:  # noqa: BLE001
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    if line.get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: asked for %d GPUs, %s ranks joined\n" % (args.gpus, line.get("n_gpus")))
+        return 1
+    return 0
+
+
+# =====================================================================================================================
+# engines: one predictor on its own stream (HipEngine), or a stand-in without a device (DryEngine; PLHIP_BENCH_DRYRUN=1,
+# used by the CPU tests of the multi-process control flow: spawn, rendezvous, scatter, per-step gather, timing)
+# =====================================================================================================================
+class HipEngine:
+    def __init__(self, torch, lite, wl, local_rank, dev, net, rows, image, cfg):
+        self.torch = torch
+        self.stream = torch.cuda.Stream(dev)
+        self.pred = lite.Predictor(local_rank, stream=self.stream.cuda_stream)
+        if cfg["model"] == "conv":
+            self.pred.add_feed("image", image.shape, lite.PREC_INT8)
+            self.pred.add_io_copy("image", "xd", True)
+            o = net["ops"][0]
+            p = o["pad"]
+            self.pred.add_conv("conv2d", "xd", o["name"], o["w"], o["bias"], (o["stride"],) * 2, (p, p, p, p), (1, 1), 1, o["act"],
+                               0.0, float(o["in_scale"]), o["w_scale"], float(o["out_scale"]), True)
+            self.out_var, self.plan = o["name"], None
+        else:
+            wl.emit_graph(self.pred, net, rows)
+            self.plan = self.pred.graph_plan()
+            self.pred.graph_lower()
+            self.out_var = net["output"]
+        self.pred.set_input("image", image)
+        self.pred.run(skip_io_copy=False)  # uploads the feed; PrepareForRun (weight pack, scale fold) everywhere
+        self.pred.sync()
+
+    def run(self):
+        self.pred.run(skip_io_copy=True)
+
+    def stage(self, dst, nbytes):
+        self.pred.copy_var_to_device(self.out_var, dst.data_ptr(), nbytes)
+
+    def record(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def wait_event(self, ev):
+        if ev is not None:
+            self.stream.wait_event(ev)
+
+    def close(self):
+        self.pred.close()
+
+
+class DryEngine:
+    """No device, no compute: "probabilities" whose first column is the global image index (so that the gathered result
+    can be checked for order and completeness)."""
+
+    def __init__(self, torch, lo, rows, classes):
+        self.fake = torch.zeros((rows, classes), dtype=torch.float32)
+        self.fake[:, 0] = torch.arange(lo, lo + rows, dtype=torch.float32)
+        self.plan = None
+
+    def run(self):
+        time.sleep(0.0005)
+
+    def stage(self, dst, nbytes):
+        dst[:self.fake.shape[0]].copy_(self.fake)
+
+    def record(self):
+        return None
+
+    def wait_event(self, ev):
+        pass
+
+    def close(self):
+        pass
+
+
+def build_net(wl, cfg, res):
+    import numpy as np
+    if cfg["model"] == "mobilenet_v1":
+        return wl.mobilenet_v1_net(seed=1234, res=res)
+    if cfg["model"] == "resnet50":
+        return wl.resnet50_net(res=res)
+    if cfg["model"] == "mobilenet_v2":
+        return wl.mobilenet_v2_net(res=res)
+    # c2: the reference test's scale convention (conv_int8_compute_test.cc:190-203)
+    rng = np.random.default_rng(2000)
+    cin, cout, k = 64, 128, 3
+    op = dict(op="conv2d", name="y", src="image", w=rng.integers(-127, 128, (cout, cin, k, k)).astype(np.int8),
+              bias=rng.uniform(-1, 1, cout).astype(np.float32), stride=1, pad=1, groups=1, act=1, act_coef=0.0,
+              in_scale=np.float32(1 / 127.0), w_scale=np.full(cout, 1 / 127.0, np.float32), out_scale=np.float32(cin * k * k / 127.0))
+    return dict(ops=[op], input="image", input_shape=(cin, 56, 56), output="y", shapes={"y": (cout, 56, 56)})
+
+
+def cpu_baseline(cfg, net, seconds):
+    """The reference algorithm restated for the host (oracle/): im2col + int8 GEMM over (batch, group) for the dense convs
+    (conv_impl.cc:490-598 structure), direct loops for depthwise, fused float epilogue, fp32 pool / add, OpenMP.
+    Bounded by time; batch 1 per pass like the reference's own benchmark (benchmark.md:35-39)."""
+    import numpy as np
+    from oracle import graph_oracle, plref
     rng = np.random.default_rng(99)
-    layers = wl.mobilenet_v1_layers()
+    c, h, w = net["input_shape"]
     done, t0 = 0, time.perf_counter()
     while True:
-        x = plref.calib_f32_to_i8(rng.uniform(-1, 1, (1, 3, 224, 224)).astype(np.float32), float(W["input_scale"]))
-        for i, (name, op, cin, cout, k, s, p, g, hin) in enumerate(layers):
-            L = W[name]
-            sh = plref.shape(1, cin, x.shape[2], x.shape[3], cout, k, k, (p, p, p, p), (s, s), (1, 1), g)
-            x, _ = plref.conv2d(sh, x, L["w"], L["bias"], float(L["in_scale"]), L["w_scale"], float(L["out_scale"]), 1, 0.0,
-                                i != len(layers) - 1, via_gemm=(g == 1))
-        pool = plref.global_avg_pool(x)
-        q = plref.calib_f32_to_i8(pool, float(W["pool_scale"]))
-        F = W["fc"]
-        logits, _ = plref.fc(q.reshape(1, -1), F["w"], F["bias"], (F["w_scale"] * np.float32(F["in_scale"])).astype(np.float32), False, False)
-        plref.softmax(logits)
+        if cfg["model"] == "conv":
+            o = net["ops"][0]
+            x = rng.integers(-127, 128, (1, c, h, w)).astype(np.int8)
+            sh = plref.shape(1, c, h, w, o["w"].shape[0], 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)
+            plref.conv2d(sh, x, o["w"], o["bias"], float(o["in_scale"]), o["w_scale"], float(o["out_scale"]), 1, 0.0, True, via_gemm=True)
+        else:
+            graph_oracle.forward(plref, net, rng.uniform(-1, 1, (1, c, h, w)).astype(np.float32), keep=set(), via_gemm=True)
         done += 1
         el = time.perf_counter() - t0
-        if el >= seconds or done >= 100000:  # bounded by time (default 12 s of CPU work)
+        if el >= seconds or done >= 100000:
             break
-    return {"value": round(done / el, 2), "unit": "img/s", "cores": int(os.environ["OMP_NUM_THREADS"]),
-            "kind": "port",
-            "sample": "%d images of the same MobileNetV1-INT8 graph, batch 1 each, %.1f s; oracle/plref.c restatement of the "
-                      "reference's im2col+GEMM int8 path (its ARM NEON kernels cannot run on x86; its x86 backend has no "
-                      "INT8 kernels)" % (done, el)}
+    return {"value": round(done / el, 2), "unit": "img/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+            "sample": "%d images of the same graph, batch 1 each, %.1f s; oracle/ restatement of the reference's im2col+GEMM int8 "
+                      "path (its ARM NEON kernels cannot run on x86; its x86 backend has no INT8 kernels)" % (done, el)}
 
 
 def main():
     args = parse()
-    # the CPU baseline's OpenMP team = the cores this process may actually use (not every core of the host)
-    # (capped at 32: the per-layer GEMMs of one image are too small to feed more threads — 256 threads measured slower)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
+    cfg = dict(CONFIGS[args.config])
+    if cfg["model"] == "conv" and world > 1:
+        sys.stderr.write("bench.py: config c2 is a single-GPU op benchmark\n")
+        sys.exit(2)
+    dry = os.environ.get("PLHIP_BENCH_DRYRUN") == "1"
+    # the CPU baseline's OpenMP team = the cores this process may actually use (capped at 32: the per-layer GEMMs of one
+    # image are too small to feed more threads)
     os.environ.setdefault("OMP_NUM_THREADS", str(min(32, len(os.sched_getaffinity(0)))))
+    import numpy as np
     import torch
     import torch.distributed as dist
+    import queue
+    import threading
     import __graft_entry__ as ge
     ge.import_package()
     lite = importlib.import_module("paddle_lite_amd.liteapi")
     wl = importlib.import_module("paddle_lite_amd.workloads")
     sharding = importlib.import_module("paddle_lite_amd.sharding")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # Rehearsal on a one-GPU box (never used by the driver): PLHIP_BENCH_SAME_GPU=1 puts every rank on device 0 and
-    # PLHIP_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so that the N > 1 control flow
-    # (weight broadcast, staging copies, pipelined gather, max-over-ranks timing) can be exercised end to end.
+    # PLHIP_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
     if os.environ.get("PLHIP_BENCH_SAME_GPU") == "1":
         local_rank = 0
-    backend = os.environ.get("PLHIP_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("PLHIP_BENCH_BACKEND", "gloo" if dry else "nccl")
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("only %d of %d ranks joined" % (dist.get_world_size(), args.gpus))
 
-    # ---- weights: rank 0 generates, RCCL broadcast over xGMI, every rank builds its predictor from the bytes ----
-    W = wl.make_mobilenet_v1_weights(seed=1234) if rank == 0 else None
-    W = sharding.broadcast_weights(W, dist, dev, rank, world)
+    # ---- work split ----
+    scaling = args.scaling or cfg.get("scaling", "weak")
+    per_gpu = args.batch or cfg["batch"]
+    if scaling == "strong":
+        global_batch = args.global_batch or cfg.get("global_batch", per_gpu)
+    else:
+        global_batch = per_gpu * world
+    lo, hi = sharding.shard_range(global_batch, rank, world)
+    rows = hi - lo
+    max_rows = max(sharding.shard_range(global_batch, r, world)[1] - sharding.shard_range(global_batch, r, world)[0]
+                   for r in range(world))
+    if rows < 1:
+        raise SystemExit("global batch %d leaves rank %d without work" % (global_batch, rank))
 
-    import queue
-    import threading
+    # ---- network: rank 0 generates, RCCL broadcast over xGMI, every rank builds its predictors from the bytes ----
+    net = build_net(wl, cfg, args.res) if rank == 0 else None
+    net = sharding.broadcast_net(net, dist, dev, rank, world)
+    classes = net["shapes"][net["output"]][0] * net["shapes"][net["output"]][1] * net["shapes"][net["output"]][2]
+
+    # ---- ONE global batch, generated on rank 0 and scattered (device to device over xGMI), resident before timing ----
+    c, h, w = net["input_shape"]
+    images = None
+    if rank == 0 and not dry:
+        rng = np.random.default_rng(1000)
+        if cfg["model"] == "conv":
+            images = rng.integers(-127, 128, (global_batch, c, h, w)).astype(np.int8)
+        else:
+            images = rng.uniform(-1, 1, (global_batch, c, h, w)).astype(np.float32)
+    if dry:
+        image = None
+    elif cfg["model"] == "conv":
+        image = images
+    else:
+        image = sharding.scatter_batch(images, global_batch, (c, h, w), dist, dev, rank, world)
+        images = None
+
     P = max(1, args.inflight)
-    S = max(1, args.streams)
-    if S > 1:
-        P = 1  # --streams (batch split inside one step) and --inflight (whole batches) are alternatives
-    assert args.batch % S == 0, "--batch must be divisible by --streams"
-    sub = args.batch // S
-    main_stream = torch.cuda.current_stream(dev)
-    streams = [main_stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-    preds = [None] * S
-    rng = np.random.default_rng(1000 + rank)
-    images = [rng.uniform(-1, 1, (sub, 3, 224, 224)).astype(np.float32) for _ in range(S)]
+    out_bytes = rows * classes * (1 if cfg["model"] == "conv" else 4)
+    engines, errs = [None] * P, []
 
-    p_bytes = (args.batch if P > 1 else sub) * wl.NUM_CLASSES * 4
-    # N > 1: per-step result gather, double buffered so that the RCCL all_gather of step s overlaps step s+1
-    gather = (sharding.PipelinedGather(torch.empty((args.batch, wl.NUM_CLASSES), dtype=torch.float32, device=dev), dist, world)
-              if world > 1 else None)
-    loc_ptr = [0]  # device address of the current step's staging buffer (written by run_steps, read by the workers)
-    loc_ready = [None]  # event on the main stream: the collective that last read that buffer has been waited for
+    # ---- per-step result gather (N > 1): DEPTH staging slots; step s uses slot s % DEPTH.  The predictor thread stages
+    # its probabilities behind the slot's previous collective (event) and tells the coordinator (queue, no reply needed);
+    # the coordinator (this thread) issues the collectives in step order on a stream that carries no compute, so every
+    # rank issues them in the same order and the all_gather of step s overlaps the kernels of the following steps. ----
+    DEPTH = 2 * P + 2
+    if world > 1:
+        local = [torch.zeros((max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
+        gathered = [torch.empty((world * max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
+        slot_free = [threading.Semaphore(1) for _ in range(DEPTH)]
+        slot_event = [None] * DEPTH
+        pending = [None] * DEPTH
+    coord_stream = None if dry else torch.cuda.Stream(dev)
 
-    class Worker(threading.Thread):
-        """One predictor, one host thread, one HIP stream (TargetWrapperHip state is per thread)."""
+    class Flight(threading.Thread):
+        """Predictor i runs the steps i, i+P, i+2P, ... as whole steps on its own stream."""
 
         def __init__(self, i):
             super().__init__(daemon=True)
-            self.i, self.cmd, self.done, self.err = i, threading.Semaphore(0), threading.Semaphore(0), None
-            self.step_done = threading.Semaphore(0)
-            self.go = threading.Semaphore(0)
-            self.events = []
-            self.n = 0
-            self.alive = True
+            self.i, self.cmd, self.done = i, threading.Semaphore(0), threading.Semaphore(0)
+            self.doneq = queue.Queue()
+            self.n, self.base, self.alive, self.err = 0, 0, True, None
 
         def run(self):
             try:
-                torch.cuda.set_device(local_rank)
-                p = lite.Predictor(local_rank, stream=streams[self.i].cuda_stream)
-                wl.build_mobilenet_v1(p, W, sub)
-                p.set_input("image", images[self.i])
-                p.run(skip_io_copy=False)  # uploads the feed; PrepareForRun (weight pack, scale fold) everywhere
-                p.sync()
-                preds[self.i] = p
+                if dry:
+                    engines[self.i] = DryEngine(torch, lo, rows, classes)
+                else:
+                    torch.cuda.set_device(local_rank)
+                    engines[self.i] = HipEngine(torch, lite, wl, local_rank, dev, net, rows, image, cfg)
             except Exception as e:  # noqa: BLE001
                 self.err = e
             self.done.release()
@@ -191,99 +353,37 @@ def main():
                 if not self.alive:
                     break
                 try:
-                    for s_ in range(self.n):
-                        preds[self.i].run(skip_io_copy=True)
-                        if world > 1:  # stage this shard's probabilities for the all_gather of step s_
-                            self.go.acquire()  # the main thread has picked this step's staging buffer
-                            streams[self.i].wait_event(loc_ready[0])  # ... and its previous collective is done
-                            preds[self.i].copy_var_to_device("prob", loc_ptr[0] + self.i * p_bytes, p_bytes)
-                            self.events[s_].record(streams[self.i])
-                            self.step_done.release()
-                except Exception as e:  # noqa: BLE001
-                    self.err = e
-                self.done.release()
-
-    class FlightWorker(threading.Thread):
-        """--inflight: predictor i runs the steps i, i+P, i+2P, ... as whole batches on its own stream."""
-
-        def __init__(self, i):
-            super().__init__(daemon=True)
-            self.i, self.cmd, self.done, self.err = i, threading.Semaphore(0), threading.Semaphore(0), None
-            self.ptrq, self.doneq = queue.Queue(), queue.Queue()
-            self.stream = torch.cuda.Stream(dev)
-            self.n = 0
-            self.alive = True
-            self.pred = None
-
-        def run(self):
-            try:
-                torch.cuda.set_device(local_rank)
-                p = lite.Predictor(local_rank, stream=self.stream.cuda_stream)
-                wl.build_mobilenet_v1(p, W, args.batch)
-                p.set_input("image", images[0])
-                p.run(skip_io_copy=False)
-                p.sync()
-                self.pred = p
-            except Exception as e:  # noqa: BLE001
-                self.err = e
-            self.done.release()
-            while True:
-                self.cmd.acquire()
-                if not self.alive:
-                    break
-                try:
+                    e = engines[self.i]
                     for s_ in range(self.i, self.n, P):
-                        self.pred.run(skip_io_copy=True)
+                        e.run()
                         if world > 1:
-                            # stage this step's probabilities into the buffer the coordinator picked for step s_
-                            ptr, ready = self.ptrq.get()
-                            self.stream.wait_event(ready)  # the collective that last read this buffer has finished
-                            self.pred.copy_var_to_device("prob", ptr, p_bytes)
-                            ev = torch.cuda.Event()
-                            ev.record(self.stream)
-                            self.doneq.put(ev)
-                except Exception as e:  # noqa: BLE001
-                    self.err = e
+                            b = (self.base + s_) % DEPTH
+                            slot_free[b].acquire()      # host: the collective that last read this slot has been ISSUED
+                            e.wait_event(slot_event[b])  # device: ... and will have FINISHED before the copy below
+                            e.stage(local[b], out_bytes)
+                            self.doneq.put(e.record())
+                except Exception as ex:  # noqa: BLE001
+                    self.err = ex
                 self.done.release()
 
-    flights = [FlightWorker(i) for i in range(P)] if P > 1 else []
+    flights = [Flight(i) for i in range(P)]
     for f_ in flights:
         f_.start()
-    workers = [Worker(i) for i in range(1, S)]
-    for w_ in workers:
-        w_.start()
-    pred = lite.Predictor(local_rank, stream=main_stream.cuda_stream)
-    out_name = wl.build_mobilenet_v1(pred, W, sub)
-    pred.set_input("image", images[0])
-    pred.run(skip_io_copy=False)
-    pred.sync()
-    preds[0] = pred
-    for w_ in workers + flights:
-        w_.done.acquire()
-        if w_.err:
-            raise w_.err
-    n_inst = pred.num_instructions()
-    names = pred.kernel_names()
-    io_idx = [i for i, n in enumerate(names) if n.startswith("io_copy")]
-    body = [i for i in range(n_inst) if i not in io_idx]
+    for f_ in flights:
+        f_.done.acquire()
+        if f_.err:
+            raise f_.err
+    step_base = [0]
+    last_gather = [None]
 
-    def run_steps_inflight(n):
-        """n steps in total, dealt round-robin over the P predictors; this thread only coordinates.  N > 1: the
-        collectives are issued here, in step order (every rank issues them in the same order), on the main stream, which
-        carries no compute: the RCCL all_gather of step s overlaps the kernels of the following steps."""
+    def run_steps(n):
+        """n steps in total, dealt round-robin over the P predictors; this thread only coordinates."""
         for f_ in flights:
-            f_.n = n
+            f_.n, f_.base = n, step_base[0]
             f_.cmd.release()
         if world > 1:
-            tr = [0.0, 0.0, 0.0] if os.environ.get("PLHIP_BENCH_TRACE") else None
             for s_ in range(n):
                 f_ = flights[s_ % P]
-                t_a = time.perf_counter()
-                buf = gather.stage_buffer()  # main stream is now ordered behind the collective that last read `buf` ...
-                ready = torch.cuda.Event()
-                ready.record(main_stream)    # ... and the predictor's stream will be, through this event
-                f_.ptrq.put((buf.data_ptr(), ready))
-                t_b = time.perf_counter()
                 while True:
                     try:
                         ev = f_.doneq.get(timeout=1.0)
@@ -291,173 +391,188 @@ def main():
                     except queue.Empty:
                         if f_.err:
                             raise f_.err
-                t_c = time.perf_counter()
-                main_stream.wait_event(ev)
-                gather.launch()
-                if tr:
-                    tr[0] += t_b - t_a
-                    tr[1] += t_c - t_b
-                    tr[2] += time.perf_counter() - t_c
-            if tr:
-                print("rank %d coordinator: %d steps, stage_buffer %.1f ms, wait for predictor %.1f ms, launch %.1f ms" % (
-                    rank, n, 1e3 * tr[0], 1e3 * tr[1], 1e3 * tr[2]), file=sys.stderr)
+                b = (step_base[0] + s_) % DEPTH
+                if dry:
+                    pending[b] = dist.all_gather_into_tensor(gathered[b], local[b], async_op=True)
+                    pending[b].wait()
+                else:
+                    with torch.cuda.stream(coord_stream):
+                        coord_stream.wait_event(ev)
+                        pending[b] = dist.all_gather_into_tensor(gathered[b], local[b], async_op=True)
+                        pending[b].wait()  # stream-level: coord_stream (no compute on it) is ordered behind the collective
+                        fe = torch.cuda.Event()
+                        fe.record(coord_stream)
+                    slot_event[b] = fe
+                last_gather[0] = gathered[b]
+                slot_free[b].release()
         for f_ in flights:
             f_.done.acquire()
             if f_.err:
                 raise f_.err
-        if world > 1:
-            gather.drain()
+        step_base[0] += n
+        if world > 1 and not dry:
+            coord_stream.synchronize()  # every step's result is complete inside the timed region
 
-    def run_steps(n):
-        """n steps on every stream of this GPU; the other predictors run on their own host threads."""
-        if P > 1:
-            return run_steps_inflight(n)
-        for w_ in workers:
-            w_.n = n
-            w_.events = [torch.cuda.Event() for _ in range(n)] if world > 1 else []
-            w_.cmd.release()
-        for s_ in range(n):
-            pred.run(skip_io_copy=True)
-            if world > 1:
-                # result gather over xGMI: every predictor stages its [sub, 1000] probabilities into this step's buffer
-                # (device-to-device, on its own stream); the main stream waits for them and starts the asynchronous RCCL
-                # all_gather, which overlaps the next step (the buffer is waited for two steps later)
-                loc_ptr[0] = gather.stage_buffer().data_ptr()
-                loc_ready[0] = torch.cuda.Event()
-                loc_ready[0].record(main_stream)
-                for w_ in workers:
-                    w_.go.release()
-                pred.copy_var_to_device("prob", loc_ptr[0], p_bytes)
-                for w_ in workers:
-                    w_.step_done.acquire()
-                    main_stream.wait_event(w_.events[s_])
-                gather.launch()
-        for w_ in workers:
-            w_.done.acquire()
-            if w_.err:
-                raise w_.err
+    def sync_all():
+        if not dry:
+            torch.cuda.synchronize(dev)
         if world > 1:
-            gather.drain()  # every step's result is complete inside the timed region
+            dist.barrier()
+        if not dry:
+            torch.cuda.synchronize(dev)
 
     run_steps(args.warmup)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync_all()
     t0 = time.perf_counter()
     run_steps(args.steps)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    stream = main_stream
 
-    # ---- informational: the same steps strictly serial on one stream (what one predictor alone delivers) ----
-    serial = None
-    if rank == 0 and P > 1:
-        for _ in range(3):
-            pred.run(skip_io_copy=True)
-        torch.cuda.synchronize(dev)
-        ts = time.perf_counter()
-        for _ in range(args.steps):
-            pred.run(skip_io_copy=True)
-        torch.cuda.synchronize(dev)
-        es = time.perf_counter() - ts
-        serial = {"value": round(args.batch * args.steps / es, 1), "unit": "img/s", "ms_per_step": round(1e3 * es / args.steps, 4),
-                  "note": "one predictor, one stream, steps back to back (this GPU only)"}
+    # ---- outside the timed region: the gathered result of the last step is complete and in rank-major image order ----
+    if world > 1 and last_gather[0] is not None:
+        g_ = last_gather[0].float().cpu().numpy().reshape(world, max_rows, classes)
+        for r in range(world):
+            l_, h_ = sharding.shard_range(global_batch, r, world)
+            blk = g_[r, :h_ - l_]
+            if dry:
+                assert np.array_equal(blk[:, 0], np.arange(l_, h_, dtype=np.float32)), "gathered rows out of order"
+            else:
+                assert np.all(np.isfinite(blk)) and np.allclose(blk.sum(-1), 1.0, rtol=1e-3), "gathered probabilities are not distributions"
 
-    # ---- per-launch kernel time, live, HIP events on the launch stream (rank 0) ----
-    roof, fam_out = None, {}
-    if rank == 0:
-        # One event pair brackets INNER back-to-back launches of the same instruction: a pair around nothing already
-        # reads ~4.7 us on this stack, so a pair per launch overstated every kernel by ~3 us (rocprofv3's per-kernel
-        # averages of the serial run were 18.3 us vs 21.6 us here); with 4 launches per pair the residue is < 1 us.
+    eng0 = engines[0]
+    pred = None if dry else eng0.pred
+    serial, roof, fam_out = None, None, {}
+    if rank == 0 and not dry:
+        stream = eng0.stream
+        # ---- informational: the same steps strictly serial on one stream (what one predictor alone delivers) ----
+        if P > 1:
+            for _ in range(3):
+                eng0.run()
+            torch.cuda.synchronize(dev)
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                eng0.run()
+            torch.cuda.synchronize(dev)
+            es = time.perf_counter() - ts
+            serial = {"value": round(rows * args.steps / es, 1), "unit": "img/s", "ms_per_step": round(1e3 * es / args.steps, 4),
+                      "note": "one predictor, one stream, steps back to back (this GPU's shard only): a step LATENCY"}
+
+        # ---- per-launch kernel time, live, HIP events on the launch stream.  One event pair brackets INNER back-to-back
+        # launches of the same instruction: a pair around nothing already reads ~4.7 us on this stack, so a pair per
+        # launch overstated every kernel by ~3 us against rocprofv3's averages; with 4 launches per pair the residue is < 1 us.
+        names = pred.kernel_names()
+        body = [i for i, n_ in enumerate(names) if not n_.startswith("io_copy")]
         reps, INNER = 5, 4
-        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in body] for _ in range(reps)]
-        for r in range(reps):
-            for j, i in enumerate(body):
-                ev[r][j][0].record(stream)
-                for _ in range(INNER):
-                    pred.run_instruction(i)
-                ev[r][j][1].record(stream)
+        with torch.cuda.stream(stream):
+            ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in body] for _ in range(reps)]
+            for r in range(reps):
+                for j, i in enumerate(body):
+                    ev[r][j][0].record(stream)
+                    for _ in range(INNER):
+                        pred.run_instruction(i)
+                    ev[r][j][1].record(stream)
         torch.cuda.synchronize(dev)
         per_inst = {i: float(np.median([ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(reps)])) / INNER
                     for j, i in enumerate(body)}
-        costs = layer_costs(wl, sub)
-        layer_names = [l[0] for l in wl.mobilenet_v1_layers()]
-        conv_idx = {}
+        if cfg["model"] == "conv":
+            o = net["ops"][0]
+            cout, cin, k, _ = o["w"].shape
+            costs = [dict(name="image", family="io_copy", ops=0, bytes=0),
+                     dict(name="y", family="conv3x3", ops=2 * rows * cout * 56 * 56 * cin * k * k,
+                          bytes=rows * (cin * 56 * 56 + cout * 56 * 56) + o["w"].size)]
+        else:
+            costs = wl.program_costs(net, rows, eng0.plan)
+        assert len(costs) == len(names), (len(costs), len(names))
         for i in body:
-            if names[i].startswith("conv2d") or names[i].startswith("depthwise_conv2d"):
-                conv_idx[layer_names[len(conv_idx)]] = i
-        for key, c in costs.items():
-            ms = sum(per_inst[conv_idx[n]] for n in c["names"])
-            fam_out[key] = {"launches": len(c["names"]), "ms": round(ms, 4), "GB/s": round(c["bytes"] / ms / 1e6, 1),
-                            "TOP/s": round(c["ops"] / ms / 1e9, 2), "alg_bytes": c["bytes"], "ops": c["ops"]}
+            f = fam_out.setdefault(costs[i]["family"], {"launches": 0, "ms": 0.0, "alg_bytes": 0, "ops": 0})
+            f["launches"] += 1
+            f["ms"] += per_inst[i]
+            f["alg_bytes"] += costs[i]["bytes"]
+            f["ops"] += costs[i]["ops"]
+        for f in fam_out.values():
+            f["GB/s"] = round(f["alg_bytes"] / f["ms"] / 1e6, 1)
+            f["TOP/s"] = round(f["ops"] / f["ms"] / 1e9, 2)
+            f["ms"] = round(f["ms"], 4)
         if args.layer_table:
-            for n in layer_names:
-                print("%-6s %8.4f ms  %s" % (n, per_inst[conv_idx[n]], names[conv_idx[n]]), file=sys.stderr)
-            other = sum(v for i, v in per_inst.items() if i not in conv_idx.values())
-            print("other (calib/pool/fc/softmax) %.4f ms" % other, file=sys.stderr)
-        # the dominant family; pointwise and depthwise are within a few % of each other, so the MFMA GEMM family keeps the
-        # label unless another one is clearly (> 10 %) larger -- otherwise `roofline.kernel` would flip from run to run
-        dom = max(fam_out, key=lambda k: fam_out[k]["ms"])
-        if dom != "pointwise1x1" and fam_out[dom]["ms"] < 1.10 * fam_out["pointwise1x1"]["ms"]:
+            for i in body:
+                print("%-28s %-16s %8.4f ms  %7.1f GB/s %7.1f TOP/s  %s" % (
+                    costs[i]["name"], costs[i]["family"], per_inst[i], costs[i]["bytes"] / per_inst[i] / 1e6,
+                    costs[i]["ops"] / per_inst[i] / 1e9, names[i]), file=sys.stderr)
+        # the dominant family (pointwise keeps the label unless another one is clearly, > 10 %, larger: otherwise
+        # `roofline.kernel` would flip from run to run on MobileNetV1, where pointwise and depthwise are within a few %)
+        dom = max(fam_out, key=lambda k_: fam_out[k_]["ms"])
+        if "pointwise1x1" in fam_out and dom != "pointwise1x1" and fam_out[dom]["ms"] < 1.10 * fam_out["pointwise1x1"]["ms"]:
             dom = "pointwise1x1"
         d = fam_out[dom]
-        hbm_frac = d["GB/s"] / HBM_PEAK_GBS
-        # HBM-side traffic per launch from the committed PMC passes (tools/pmc_traffic.py over `rocprofv3 --pmc FETCH_SIZE`
-        # and `--pmc WRITE_SIZE` runs of this script, batch 128): FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B;
-        # verified here on calib_f32_to_i8 and on the 32->64 pointwise layer, both = 0.50 of the known bytes) + WRITE_SIZE
-        traffic = None
+        ai = d["ops"] / max(1, d["alg_bytes"])
+        mfma_bound = ai > BALANCE_OPS_PER_BYTE
+        # HBM-side traffic per launch: from the PMC passes committed under profiles/ (tools/pmc_traffic.py over
+        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script: FETCH_SIZE x2 per the gfx950 correction
+        # + WRITE_SIZE); a file, not a live counter -> named in traffic_source, null when absent for this config
+        traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.batch == 128:
+        if os.path.exists(tpath) and args.config == "c3" and rows == 128:
             try:
-                t_ = json.load(open(tpath)).get(dom)
-                traffic = round(t_["fetch_bytes_per_launch_x2"] + t_["write_bytes_per_launch"]) if t_ else None
-            except Exception:
+                tj = json.load(open(tpath))
+                t_ = tj.get(dom)
+                if t_:
+                    traffic = round(t_["fetch_bytes_per_launch_x2"] + t_["write_bytes_per_launch"])
+                    tsrc = "profiles/pmc_traffic.json @ %s (not measured in this run)" % tj.get("commit", "round 1")
+            except Exception:  # noqa: BLE001
                 traffic = None
-        roof = {"kernel": dom, "bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(hbm_frac, 4), "traffic": traffic,
+        roof = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",
+                "achieved": d["TOP/s"] if mfma_bound else d["GB/s"], "peak": round(MFMA_I8_PEAK_TOPS, 1) if mfma_bound else HBM_PEAK_GBS,
+                "unit": "TOP/s" if mfma_bound else "GB/s",
+                "frac": round((d["TOP/s"] / MFMA_I8_PEAK_TOPS) if mfma_bound else (d["GB/s"] / HBM_PEAK_GBS), 4),
+                "traffic": traffic, "traffic_source": tsrc,
                 "avg_launch_ms": round(d["ms"] / d["launches"], 5), "launches_per_step": d["launches"],
-                "alg_bytes_per_launch": round(d["alg_bytes"] / d["launches"]),
+                "alg_bytes_per_launch": round(d["alg_bytes"] / d["launches"]), "alg_ops_per_byte": round(ai, 1),
+                "hbm_GB/s": d["GB/s"], "hbm_frac": round(d["GB/s"] / HBM_PEAK_GBS, 4),
                 "mfma_TOP/s": d["TOP/s"], "mfma_frac_of_dense_i8_peak": round(d["TOP/s"] / MFMA_I8_PEAK_TOPS, 4),
-                "note": "algorithmic bytes = int8 in + out + weights once per layer (SURVEY.md 8d), summed over the "
-                        "family's launches of one step, / summed launch time (HIP events on the launch stream, 4 launches per event pair)"}
+                "note": "family aggregate: algorithmic bytes = unique input + weights + output once per launch (SURVEY.md 8d), "
+                        "summed over the family's launches of one step, / summed launch time (HIP events on the launch "
+                        "stream, 4 launches per event pair); bound = mfma iff ops/byte > %.0f" % BALANCE_OPS_PER_BYTE}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(wl, W, args.cpu_seconds)  # OMP_NUM_THREADS was pinned to the usable cores in main()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
+        cpu = cpu_baseline(cfg, net, args.cpu_seconds)
 
     if rank == 0:
-        total_imgs = world * args.batch * args.steps
+        total_imgs = global_batch * args.steps
         val = total_imgs / elapsed
-        ops_per_img = 2 * (sum(v for k, v in wl.mobilenet_v1_macs().items() if k != "act_bytes"))
+        stats = wl.net_stats(net) if cfg["model"] != "conv" else {"conv_kxk": 128 * 56 * 56 * 64 * 9}
+        ops_per_img = 2 * sum(stats.values())
         line = {
-            "metric": "INT8 images/sec MobileNetV1 224x224", "value": round(val, 1), "unit": "img/s",
+            "metric": cfg["metric"], "value": round(val, 1), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "MobileNetV1 INT8 full graph 224x224 (27 int8 convs + pool + fc + softmax), "
-                                   "random-init weights, batch %d per step and GPU (%s), input resident in HBM" % (
-                                       args.batch, ("%d predictors / HIP streams, each running whole batches: %d steps in flight" % (P, P))
-                                       if P > 1 else ("%d predictor thread(s)/stream(s) x %d images" % (S, sub))),
-                       "steps_in_flight": P,
-                       "global_batch": world * args.batch, "parallelism": "batch-split x%d, RCCL weight broadcast + logits all_gather" % world},
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "int8", "data": "synthetic" if not dry else "dryrun-no-compute",
+            "config": {"workload": "%s, random-init weights, %d images per step and GPU (%s), input resident in HBM" % (
+                cfg["title"], rows, ("%d predictors / HIP streams, each running whole steps: %d steps in flight" % (P, P))
+                if P > 1 else "1 predictor, serial steps"),
+                       "name": args.config, "steps_in_flight": P, "global_batch": global_batch,
+                       "parallelism": "batch split x%d (shard_range), RCCL network broadcast + input scatter at init, "
+                                      "asynchronous all_gather of the probabilities per step" % world},
+            "ms_per_step_note": "elapsed / steps with %d steps in flight: an aggregate issue interval, not a step latency "
+                                "(see single_stream)" % P,
             "whole_graph_TOP/s": round(val * ops_per_img / 1e12, 2),
             "whole_graph_frac_of_i8_mfma_peak": round(val * ops_per_img / 1e12 / MFMA_I8_PEAK_TOPS, 4),
             "single_stream": serial, "roofline": roof, "kernels": fam_out, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    for w_ in workers + flights:
-        w_.alive = False
-        w_.cmd.release()
-    pred.close()
+        sys.stdout.flush()
+    for f_ in flights:
+        f_.alive = False
+        f_.cmd.release()
+    for e in engines:
+        if e is not None:
+            e.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

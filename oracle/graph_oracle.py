@@ -1,6 +1,6 @@
 """Oracle (CPU) execution of an op-list network (paddle-lite_amd/workloads.py) with the reference's semantics.
 
-TEST INFRASTRUCTURE.  Independent of lite/api/graph_builder.cc: the kernel-pick rule and the cast placement are
+TEST INFRASTRUCTURE (only tests/, smoke() and bench.py's cpu_baseline leg import it).  Independent of lite/api/graph_builder.cc: the kernel-pick rule and the cast placement are
 restated here from the reference (static_kernel_pick_pass.cc:92-165: int8 output iff every consumer is enable_int8,
 output scale = first consumer's input scale; type_precision_cast_pass.cc:60-100: one calib per source tensor, scale of
 the first int8 consumer), and every op is computed with oracle/plref (conv / fc / calib restated from the ARM path,
@@ -45,8 +45,9 @@ def plan(net):
     return steps
 
 
-def forward(plref, net, image, keep=None):
-    """keep: optional set of variable names to retain (None = all)."""
+def forward(plref, net, image, keep=None, via_gemm=False):
+    """keep: optional set of variable names to retain (None = all).  via_gemm: dense convs through the im2col + GEMM
+    structuring of the reference kernel (same accumulators bit for bit, faster; the timed CPU baseline form)."""
     T = {net["input"]: np.ascontiguousarray(image, np.float32)}
     out = {}
 
@@ -68,7 +69,7 @@ def forward(plref, net, image, keep=None):
             sh = plref.shape(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, k, k, (p, p, p, p),
                              (o["stride"],) * 2, (1, 1), o["groups"])
             y, _ = plref.conv2d(sh, x, o["w"], o["bias"], float(o["in_scale"]), o["w_scale"], s["oscale"], o["act"],
-                                o["act_coef"], s["int8_out"])
+                                o["act_coef"], s["int8_out"], via_gemm=(via_gemm and o["groups"] == 1))
             put(o["name"], y)
         elif t == "fc":
             x = T[ins[0]]

@@ -18,8 +18,13 @@ namespace plhip {
 // FC epilogue.  flags bit 0: relu; bit 1: the reference's gemm_s8 + fill_bias_fc route (fc_compute.cc:250-266,
 // funcs.cc:24-108: product rounded, then the bias added with a second rounding) instead of the single fused
 // multiply-add of its gemv route (gemv_arm_int8.cc:47-56).  The host picks the route like check_fc_use_gemm does.
+__device__ __forceinline__ float mul_then_add_two_roundings(float a, float s, float b) {
+#pragma clang fp contract(off)  // HIP's __fmul_rn / __fadd_rn are plain operators: hipcc's default contraction fuses them
+  const float p = a * s;
+  return p + b;
+}
 __device__ __forceinline__ float fc_epilogue_f32(int acc, float s, float b, int flags) {
-  float y = (flags & 2) ? __fadd_rn(__fmul_rn((float)acc, s), b) : __fmaf_rn((float)acc, s, b);
+  float y = (flags & 2) ? mul_then_add_two_roundings((float)acc, s, b) : __fmaf_rn((float)acc, s, b);
   if (flags & 1) y = y > 0.f ? y : 0.f;
   return y;
 }

@@ -117,3 +117,76 @@ class PipelinedGather:
                 self.pending[b].wait()
                 self.pending[b] = None
 
+
+
+# ---- op-list networks (workloads.py) over the same transport ----
+def net_to_blob(net):
+    """Split an op-list network into a picklable skeleton (no arrays) and an {key: array} dict for pack_weights."""
+    arrays, ops = {}, []
+    for i, o in enumerate(net["ops"]):
+        sk = {}
+        for k, v in o.items():
+            if isinstance(v, np.ndarray):
+                arrays.setdefault("op%04d" % i, {})[k] = v
+                sk[k] = None
+            elif isinstance(v, np.generic):
+                sk[k] = ("np", str(v.dtype), v.item())
+            else:
+                sk[k] = v
+        ops.append(sk)
+    skeleton = {k: v for k, v in net.items() if k != "ops"}
+    skeleton["ops"] = ops
+    return skeleton, arrays
+
+
+def net_from_blob(skeleton, arrays):
+    net = {k: v for k, v in skeleton.items() if k != "ops"}
+    ops = []
+    for i, sk in enumerate(skeleton["ops"]):
+        o = {}
+        for k, v in sk.items():
+            if v is None and k in arrays.get("op%04d" % i, {}):
+                o[k] = arrays["op%04d" % i][k]
+            elif isinstance(v, tuple) and len(v) == 3 and v[0] == "np":
+                o[k] = np.dtype(v[1]).type(v[2])
+            else:
+                o[k] = v
+        ops.append(o)
+    net["ops"] = ops
+    return net
+
+
+def broadcast_net(net, dist, device, rank, world, src=0):
+    """Rank `src` passes the network, the others None: skeleton by broadcast_object_list, every weight / scale / bias
+    array in ONE blob by dist.broadcast (RCCL over xGMI on GPUs)."""
+    if world == 1:
+        return net
+    if rank == src:
+        skeleton, arrays = net_to_blob(net)
+        meta = [skeleton]
+    else:
+        arrays, meta = None, [None]
+    dist.broadcast_object_list(meta, src=src)
+    arrays = broadcast_weights(arrays, dist, device, rank, world, src)
+    return net if rank == src else net_from_blob(meta[0], arrays)
+
+
+def scatter_batch(images, global_batch, sample_shape, dist, device, rank, world, src=0):
+    """One global batch generated on rank `src` -> every rank's contiguous shard [lo, hi) (shard_range; ragged sizes
+    allowed: shards are padded to the largest one for the collective).  Returns a numpy array [hi - lo, ...]."""
+    import torch
+    lo, hi = shard_range(global_batch, rank, world)
+    if world == 1:
+        return np.ascontiguousarray(images[lo:hi])
+    rows = max(shard_range(global_batch, r, world)[1] - shard_range(global_batch, r, world)[0] for r in range(world))
+    recv = torch.empty((rows,) + tuple(sample_shape), dtype=torch.float32, device=device)
+    parts = None
+    if rank == src:
+        parts = []
+        for r in range(world):
+            l, h = shard_range(global_batch, r, world)
+            t = torch.zeros((rows,) + tuple(sample_shape), dtype=torch.float32)
+            t[:h - l] = torch.from_numpy(np.ascontiguousarray(images[l:h]))
+            parts.append(t.to(device))
+    dist.scatter(recv, parts, src=src)
+    return recv[:hi - lo].cpu().numpy()

@@ -234,18 +234,23 @@ def mobilenet_v1_net(seed=1234, res=224):
     """MobileNetV1 in op-list form, same weights as make_mobilenet_v1_weights(seed): graph mode must arrive at exactly
     the Appendix-D program that build_mobilenet_v1 writes out by hand."""
     W = make_mobilenet_v1_weights(seed, res)
-    ops = []
+    ops, shapes = [], {}
     cur = "image"
     for (name, op, cin, cout, k, s, p, g, hin) in mobilenet_v1_layers(res):
         L = W[name]
         ops.append(dict(op=op, name=name, src=cur, w=L["w"], bias=L["bias"], stride=s, pad=p, groups=g, act=1, act_coef=0.0,
                         in_scale=L["in_scale"], w_scale=L["w_scale"]))
+        ho = (hin + 2 * p - k) // s + 1
+        shapes[name] = (cout, ho, ho)
         cur = name
-    ops.append(dict(op="pool2d", name="pool", src=cur, pooling_type="avg", ksize=7, stride=1, pad=0, global_pooling=True))
+    ops.append(dict(op="pool2d", name="pool", src=cur, pooling_type="avg", ksize=shapes[cur][1], stride=1, pad=0,
+                    global_pooling=True))
+    shapes["pool"] = (shapes[cur][0], 1, 1)
     F = W["fc"]
     ops.append(dict(op="fc", name="logits", src="pool", w=F["w"], bias=F["bias"], in_scale=F["in_scale"], w_scale=F["w_scale"]))
     ops.append(dict(op="softmax", name="prob", src="logits"))
-    return dict(ops=ops, input="image", input_shape=(3, res, res), output="prob", shapes={})
+    shapes["logits"] = shapes["prob"] = (NUM_CLASSES, 1, 1)
+    return dict(ops=ops, input="image", input_shape=(3, res, res), output="prob", shapes=shapes)
 
 
 def net_stats(net):
@@ -290,3 +295,60 @@ def emit_graph(pred, net, batch):
             raise ValueError(t)
     pred.graph_fetch(net["output"])
     return net["output"] + "/host"
+
+
+def program_costs(net, batch, plan_lines):
+    """Algorithmic work of every instruction of the lowered program (unique input + weights + output once,
+    no im2col expansion, no re-reads), aligned with `plan_lines` (GraphBuilder::Plan / Predictor.graph_plan()).
+    Returns [dict(name, family, ops, bytes)]; io_copy lines get family "io_copy" and zero cost."""
+    shapes = dict(net["shapes"])
+    shapes[net["input"]] = net["input_shape"]
+    esz = {}  # variable -> bytes per element
+
+    def numel(v):
+        base = v.replace("/target_trans", "").replace("/precision_trans", "")
+        c, h, w = shapes[base]
+        return batch * c * h * w
+
+    by_name = {o["name"]: o for o in net["ops"]}
+    out = []
+    esz[net["input"]] = 4
+    for line in plan_lines:
+        head, rest = line.split(" ", 1)
+        kv = dict(f.split("=", 1) for f in rest.split(" "))
+        ins, dst = kv["in"].split(","), kv["out"]
+        op, alias = head.split("/")
+        if op == "io_copy":
+            esz[dst] = esz.get(ins[0], 4)
+            out.append(dict(name=dst, family="io_copy", ops=0, bytes=0))
+            continue
+        if op == "calib":
+            esz[dst] = 1 if alias == "fp32_to_int8" else 4
+            out.append(dict(name=dst, family="calib", ops=0, bytes=numel(ins[0]) * esz[ins[0]] + numel(dst) * esz[dst]))
+            continue
+        o = by_name[dst]
+        if op in ("conv2d", "depthwise_conv2d", "fc"):
+            esz[dst] = 1 if alias in ("int8_out", "int8out") else 4
+            wbytes = int(o["w"].size)
+            if op == "fc":
+                macs = batch * o["w"].shape[0] * o["w"].shape[1]
+                fam = "fc"
+            else:
+                cout, cg, k, _ = o["w"].shape
+                c, h, w = shapes[dst]
+                macs = batch * h * w * cout * cg * k * k
+                cin = shapes[o["src"]][0]
+                if op == "depthwise_conv2d":
+                    fam = "depthwise%dx%d" % (k, k)
+                elif k == 1:
+                    fam = "pointwise1x1" if o["stride"] == 1 else "conv1x1s2"
+                else:
+                    fam = "stem_conv" if cin <= 4 else "conv%dx%d" % (k, k)
+            byts = sum(numel(i) * esz[i] for i in ins) + numel(dst) * esz[dst] + wbytes
+            out.append(dict(name=dst, family=fam, ops=2 * macs, bytes=byts))
+        else:
+            esz[dst] = 4
+            fam = {"pool2d": "pool2d", "elementwise_add": "elementwise_add", "fusion_elementwise_add_activation": "elementwise_add",
+                   "softmax": "softmax"}[op]
+            out.append(dict(name=dst, family=fam, ops=0, bytes=sum(numel(i) * esz[i] for i in ins) + numel(dst) * esz[dst]))
+    return out

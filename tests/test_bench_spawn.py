@@ -1,0 +1,53 @@
+"""bench.py's own N > 1 launch path on the CPU: `--gpus 2` without a launcher environment must start two rank
+processes, rendezvous (gloo here, RCCL on GPUs), broadcast the network, split one global batch with shard_range, gather
+every step's result and print ONE JSON line with n_gpus == 2.  PLHIP_BENCH_DRYRUN=1 replaces the predictor by a stand-in
+without a device (the control flow is what is tested; the numbers mean nothing and the line says so)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(PLHIP_BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_gpus_2_spawns_two_ranks_weak():
+    rc, out, err = _run(["--gpus", "2", "--steps", "7", "--warmup", "3", "--inflight", "2", "--batch", "5", "--res", "32"])
+    assert rc == 0, err[-3000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 10
+    assert line["steps"] == 7 and line["data"] == "dryrun-no-compute" and line["value"] > 0
+    assert line["metric"] == "INT8 images/sec MobileNetV1 224x224"
+
+
+def test_strong_scaling_ragged_global_batch_three_ranks():
+    # 7 images over 3 ranks -> shards of 3, 2, 2 rows: padded staging slots, rank-major order checked inside bench.py
+    rc, out, err = _run(["--gpus", "3", "--steps", "9", "--warmup", "2", "--inflight", "3", "--scaling", "strong",
+                         "--global-batch", "7", "--config", "c5", "--res", "32"])
+    assert rc == 0, err[-3000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["config"]["global_batch"] == 7
+    assert "MobileNetV2" in line["metric"]
+
+
+def test_world_size_mismatch_is_an_error():
+    rc, out, err = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and "WORLD_SIZE=2" in err and out.strip() == ""
+
+
+def test_single_process_line_shape():
+    rc, out, err = _run(["--steps", "3", "--warmup", "1", "--batch", "4", "--res", "32"])
+    assert rc == 0, err[-3000:]
+    line = json.loads(out.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line
+    assert line["n_gpus"] == 1 and line["config"]["name"] == "c3"

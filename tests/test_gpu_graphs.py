@@ -5,7 +5,7 @@ import importlib
 import numpy as np
 import pytest
 
-import graph_oracle
+from oracle import graph_oracle
 import mbv1_oracle
 
 pytestmark = pytest.mark.gpu

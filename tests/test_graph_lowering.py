@@ -1,12 +1,12 @@
 """Host logic of graph mode (lite/api/graph_builder.*): kernel pick and cast placement, checked on the CPU (no device)
-against the hand-written Appendix-D program and against tests/graph_oracle.py's independent restatement of the same
+against the hand-written Appendix-D program and against oracle/graph_oracle.py's independent restatement of the same
 reference passes; plus the oracle's new glue ops against torch's CPU ops (independent cross-check)."""
 import importlib
 
 import numpy as np
 import pytest
 
-import graph_oracle
+from oracle import graph_oracle
 
 
 @pytest.fixture(scope="module")
