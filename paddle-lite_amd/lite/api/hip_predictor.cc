@@ -32,8 +32,16 @@ Tensor* HipPredictor::NewParam(const void* host, size_t bytes, const std::vector
   return t;
 }
 
+const std::shared_ptr<HipExecState>& HipPredictor::state() {
+  if (!state_) {
+    TargetWrapperHip::SetDevice(device_);
+    state_ = TargetWrapperHip::State();
+  }
+  return state_;
+}
+
 void HipPredictor::Emit(std::shared_ptr<OpLite> op, std::unique_ptr<KernelBase> kernel) {
-  kernel->SetContext(NewContext(TARGET(kHIP), device_));
+  kernel->SetContext(NewContext(TARGET(kHIP), device_, state()));
   op->AttachKernel(kernel.get());
   program_.Add(Instruction(std::move(op), std::move(kernel)));
 }

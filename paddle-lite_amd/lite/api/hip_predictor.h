@@ -59,7 +59,10 @@ class HipPredictor {
     TargetWrapperHip::SetDevice(device_);
     program_.Run(skip_io_copy);
   }
-  void Sync() { TargetWrapperHip::StreamSync(); }
+  // The predictor's execution state (device stream + workspace): the creating thread's default state at the first
+  // instruction (after pllite_adopt_stream: the adopted stream), kept for life — Run() from any thread uses it.
+  const std::shared_ptr<HipExecState>& state();
+  void Sync() { state()->Sync(); }
   RuntimeProgram& program() { return program_; }
   std::vector<std::string> KernelNames();
 
@@ -67,6 +70,7 @@ class HipPredictor {
   void Emit(std::shared_ptr<OpLite> op, std::unique_ptr<KernelBase> kernel);
   Tensor* NewParam(const void* host, size_t bytes, const std::vector<int64_t>& dims, PrecisionType prec);
   int device_;
+  std::shared_ptr<HipExecState> state_;
   std::map<std::string, std::unique_ptr<Tensor>> vars_;
   std::vector<std::unique_ptr<Tensor>> params_;
   RuntimeProgram program_;

@@ -49,7 +49,7 @@ pllite_predictor* pllite_predictor_create(int device) {
   pllite_predictor* p = nullptr;
   if (guarded([&] {
         p = new pllite_predictor(device);
-        (void)paddle::lite::TargetWrapperHip::Ctx();  // fail here, loudly, when there is no gfx950 device
+        (void)p->pred.state();  // fail here, loudly, when there is no gfx950 device
       }) != 0) {
     delete p;
     return nullptr;
@@ -251,7 +251,7 @@ int pllite_copy_var_to_device(pllite_predictor* p, const char* name, void* dst_d
     Tensor* t = p->pred.Var(name);
     CHECK(t->target() == TARGET(kHIP)) << name << " is not device resident";
     CHECK_EQ(static_cast<int64_t>(t->memory_size()), bytes);
-    paddle::lite::TargetWrapperHip::MemcpyAsync(dst_dev, t->raw_data(), static_cast<size_t>(bytes), paddle::lite::IoDirection::DtoD);
+    p->pred.state()->MemcpyAsync(dst_dev, t->raw_data(), static_cast<size_t>(bytes), paddle::lite::IoDirection::DtoD);
   });
 }
 int pllite_kernel_names(pllite_predictor* p, char* buf, int cap) {

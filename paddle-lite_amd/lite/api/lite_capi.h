@@ -12,7 +12,10 @@ extern "C" {
 const char* pllite_last_error(void);
 /* Number of kernels registered for (op_type, kHIP, precision, layout) — registry smoke check. */
 int pllite_registered_kernels(const char* op_type, int precision, int layout);
-/* Adopt an external hipStream_t (e.g. torch's current stream) for this thread + device; call before anything else. */
+/* Adopt an external hipStream_t (e.g. torch's current stream) as the calling thread's default execution stream on
+ * `device`.  A predictor binds the default execution state (stream + workspace) of the thread that CREATES it and keeps
+ * it for life: pllite_run / pllite_run_instruction may be called from any thread (one at a time per predictor — a
+ * predictor is single-threaded like the reference's, program.cc:282-306) and always enqueue on that stream. */
 int pllite_adopt_stream(int device, void* stream);
 
 typedef struct pllite_predictor pllite_predictor;

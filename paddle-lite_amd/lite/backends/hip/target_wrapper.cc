@@ -9,17 +9,45 @@
 namespace paddle {
 namespace lite {
 
+HipExecState::HipExecState(int device, void* adopted_stream) : device_(device) {
+  const int st = adopted_stream ? plhip_ctx_create_on_stream(device, adopted_stream, &ctx_) : plhip_ctx_create(device, &ctx_);
+  if (st != 0) LOG(FATAL) << "plhip_ctx_create(" << device << ") -> " << st << ": " << plhip_last_error(nullptr);
+}
+HipExecState::~HipExecState() {
+  if (ws_) plhip_free(ctx_, ws_);
+  plhip_ctx_destroy(ctx_);
+}
+void* HipExecState::stream() const { return plhip_ctx_stream(ctx_); }
+void HipExecState::Sync() const { HIP_CALL(ctx_, plhip_stream_sync(ctx_)); }
+void* HipExecState::Workspace(size_t bytes) {
+  if (ws_bytes_ < bytes) {
+    if (ws_) {
+      Sync();  // kernels still reading the old arena must finish before it is freed
+      HIP_CALL(ctx_, plhip_free(ctx_, ws_));
+      ws_ = nullptr;
+    }
+    HIP_CALL(ctx_, plhip_malloc(ctx_, bytes, &ws_));
+    ws_bytes_ = bytes;
+  }
+  return ws_;
+}
+void HipExecState::MemcpyAsync(void* dst, const void* src, size_t size, IoDirection dir) const {
+  switch (dir) {
+    case IoDirection::HtoD: HIP_CALL(ctx_, plhip_memcpy_h2d(ctx_, dst, src, size)); break;
+    case IoDirection::DtoH: HIP_CALL(ctx_, plhip_memcpy_d2h(ctx_, dst, src, size)); break;
+    case IoDirection::DtoD: HIP_CALL(ctx_, plhip_memcpy_d2d(ctx_, dst, src, size)); break;
+    default: std::memcpy(dst, src, size);
+  }
+}
+void HipExecState::MemcpySync(void* dst, const void* src, size_t size, IoDirection dir) const {
+  MemcpyAsync(dst, src, size, dir);
+  if (dir == IoDirection::DtoD) Sync();  // h2d / d2h already complete on return (stream-ordered, then synchronised)
+}
+
 namespace {
 struct ThreadHipState {
   int device{0};
-  std::map<int, plhip_ctx*> ctx;      // per device
-  std::map<int, void*> ws;            // per device workspace
-  std::map<int, size_t> ws_bytes;
-  ~ThreadHipState() {
-    for (auto& kv : ws)
-      if (kv.second) plhip_free(ctx[kv.first], kv.second);
-    for (auto& kv : ctx) plhip_ctx_destroy(kv.second);
-  }
+  std::map<int, std::shared_ptr<HipExecState>> state;  // per device: the default state of this thread
 };
 thread_local ThreadHipState g_hip;
 }  // namespace
@@ -29,26 +57,23 @@ size_t TargetWrapperHip::GetCurDevice() { return static_cast<size_t>(g_hip.devic
 void TargetWrapperHip::SetDevice(int id) { g_hip.device = id; }
 
 void TargetWrapperHip::AdoptStream(int device, stream_t stream) {
-  CHECK(g_hip.ctx.find(device) == g_hip.ctx.end()) << "AdoptStream must precede the first use of device " << device;
-  plhip_ctx* c = nullptr;
-  int st = plhip_ctx_create_on_stream(device, stream, &c);
-  if (st != 0) LOG(FATAL) << "plhip_ctx_create_on_stream(" << device << ") -> " << st << ": " << plhip_last_error(nullptr);
-  g_hip.ctx[device] = c;
+  // replaces this thread's default state for the device: contexts created from now on run on `stream`; predictors
+  // built earlier keep the state they captured
+  g_hip.state[device] = std::make_shared<HipExecState>(device, stream);
   g_hip.device = device;
 }
 
-plhip_ctx* TargetWrapperHip::Ctx() {
-  auto it = g_hip.ctx.find(g_hip.device);
-  if (it != g_hip.ctx.end()) return it->second;
-  plhip_ctx* c = nullptr;
-  int st = plhip_ctx_create(g_hip.device, &c);
-  if (st != 0) LOG(FATAL) << "plhip_ctx_create(" << g_hip.device << ") -> " << st << ": " << plhip_last_error(nullptr);
-  g_hip.ctx[g_hip.device] = c;
-  return c;
+std::shared_ptr<HipExecState> TargetWrapperHip::State() {
+  auto it = g_hip.state.find(g_hip.device);
+  if (it != g_hip.state.end()) return it->second;
+  auto s = std::make_shared<HipExecState>(g_hip.device, nullptr);
+  g_hip.state[g_hip.device] = s;
+  return s;
 }
+plhip_ctx* TargetWrapperHip::Ctx() { return State()->ctx(); }
 
-TargetWrapperHip::stream_t TargetWrapperHip::ExecStream() { return plhip_ctx_stream(Ctx()); }
-void TargetWrapperHip::StreamSync() { HIP_CALL(Ctx(), plhip_stream_sync(Ctx())); }
+TargetWrapperHip::stream_t TargetWrapperHip::ExecStream() { return State()->stream(); }
+void TargetWrapperHip::StreamSync() { State()->Sync(); }
 
 void* TargetWrapperHip::Malloc(size_t size) {
   void* p = nullptr;
@@ -57,33 +82,10 @@ void* TargetWrapperHip::Malloc(size_t size) {
 }
 void TargetWrapperHip::Free(void* ptr) { HIP_CALL(Ctx(), plhip_free(Ctx(), ptr)); }
 
-void TargetWrapperHip::MemcpySync(void* dst, const void* src, size_t size, IoDirection dir) {
-  MemcpyAsync(dst, src, size, dir);
-  if (dir == IoDirection::DtoD) StreamSync();  // h2d / d2h already complete on return
-}
-void TargetWrapperHip::MemcpyAsync(void* dst, const void* src, size_t size, IoDirection dir) {
-  plhip_ctx* c = Ctx();
-  switch (dir) {
-    case IoDirection::HtoD: HIP_CALL(c, plhip_memcpy_h2d(c, dst, src, size)); break;
-    case IoDirection::DtoH: HIP_CALL(c, plhip_memcpy_d2h(c, dst, src, size)); break;
-    case IoDirection::DtoD: HIP_CALL(c, plhip_memcpy_d2d(c, dst, src, size)); break;
-    default: std::memcpy(dst, src, size);
-  }
-}
+void TargetWrapperHip::MemcpySync(void* dst, const void* src, size_t size, IoDirection dir) { State()->MemcpySync(dst, src, size, dir); }
+void TargetWrapperHip::MemcpyAsync(void* dst, const void* src, size_t size, IoDirection dir) { State()->MemcpyAsync(dst, src, size, dir); }
 void TargetWrapperHip::MemsetAsync(void* dst, int value, size_t size) { HIP_CALL(Ctx(), plhip_memset(Ctx(), dst, value, size)); }
-
-void* TargetWrapperHip::Workspace(size_t bytes) {
-  const int d = g_hip.device;
-  if (g_hip.ws_bytes[d] < bytes) {
-    if (g_hip.ws[d]) {
-      StreamSync();  // kernels still reading the old arena must finish before it is freed
-      Free(g_hip.ws[d]);
-    }
-    g_hip.ws[d] = Malloc(bytes);
-    g_hip.ws_bytes[d] = bytes;
-  }
-  return g_hip.ws[d];
-}
+void* TargetWrapperHip::Workspace(size_t bytes) { return State()->Workspace(bytes); }
 
 void* TargetMalloc(TargetType target, size_t size) {
   switch (target) {

@@ -24,22 +24,28 @@ template <>
 class Context<TARGET(kHIP)> {
  public:
   void InitOnce() {}
-  void Init(int dev_id, int exec_stream_id = 0) {
+  // Binds the calling thread's default execution state (TargetWrapperHip::State()) unless one was given: the state
+  // (stream + workspace) then belongs to this context, whichever thread later runs the kernel.
+  void Init(int dev_id, int exec_stream_id = 0, std::shared_ptr<HipExecState> state = nullptr) {
     device_id_ = dev_id;
     (void)exec_stream_id;
     TargetWrapperHip::SetDevice(dev_id);
+    state_ = state ? state : TargetWrapperHip::State();
   }
   int device_id() const { return device_id_; }
-  plhip_ctx* ctx() const { return TargetWrapperHip::Ctx(); }
-  void* exec_stream() const { return TargetWrapperHip::ExecStream(); }
-  void Sync() const { TargetWrapperHip::StreamSync(); }
-  // Scratch shared by every kernel of this thread+device (WorkSpace::Global_CUDA() analogue, kernel.h:91-100);
+  const std::shared_ptr<HipExecState>& state() const { return state_; }
+  plhip_ctx* ctx() const { return state_->ctx(); }
+  void* exec_stream() const { return state_->stream(); }
+  void Sync() const { state_->Sync(); }
+  // Scratch shared by every kernel of this execution state (WorkSpace::Global_CUDA() analogue, kernel.h:91-100);
   // kernels run in stream order, so one grow-only arena is enough.
-  void* workspace(size_t bytes) { return TargetWrapperHip::Workspace(bytes); }
+  void* workspace(size_t bytes) { return state_->Workspace(bytes); }
+  void MemcpySync(void* dst, const void* src, size_t size, IoDirection dir) const { state_->MemcpySync(dst, src, size, dir); }
   std::string name() const { return "HIPContext"; }
 
  private:
   int device_id_{0};
+  std::shared_ptr<HipExecState> state_;
 };
 using HIPContext = Context<TARGET(kHIP)>;
 
@@ -69,10 +75,11 @@ class KernelContext {
 };
 
 // ContextScheduler::NewContext (context.h:426-470) for the targets present here.
-inline std::unique_ptr<KernelContext> NewContext(TargetType target, int device_id = 0) {
+inline std::unique_ptr<KernelContext> NewContext(TargetType target, int device_id = 0,
+                                                 std::shared_ptr<HipExecState> state = nullptr) {
   std::unique_ptr<KernelContext> ctx(new KernelContext);
   if (target == TARGET(kHIP)) {
-    ctx->As<HIPContext>().Init(device_id);
+    ctx->As<HIPContext>().Init(device_id, 0, state);
   } else {
     ctx->As<HostContext>();
   }

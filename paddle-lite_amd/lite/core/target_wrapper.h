@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 #include "lite/api/paddle_place.h"
 #include "lite/utils/logging.h"
@@ -39,6 +40,31 @@ class TargetWrapper<TARGET(kHost)> {
     if (st__ != 0) LOG(FATAL) << "HIP: " #expr__ " -> " << st__ << ": " << plhip_last_error(ctx__); \
   } while (0)
 
+// Execution state of one predictor (or of a thread's default context): the plhip_ctx (device + HIP stream) and the
+// grow-only scratch arena.  Owned through shared_ptr by every Context<kHIP> built from it, so a predictor created on
+// thread A keeps running on ITS stream when Run() is called from thread B (the reference keeps the stream in the CUDA
+// context object, lite/backends/cuda/context.h:46-73; a thread_local alone would silently switch streams).
+class HipExecState {
+ public:
+  HipExecState(int device, void* adopted_stream);  // adopted_stream == nullptr: own stream
+  ~HipExecState();
+  HipExecState(const HipExecState&) = delete;
+  HipExecState& operator=(const HipExecState&) = delete;
+  int device() const { return device_; }
+  plhip_ctx* ctx() const { return ctx_; }
+  void* stream() const;
+  void Sync() const;
+  void* Workspace(size_t bytes);
+  void MemcpySync(void* dst, const void* src, size_t size, IoDirection dir) const;
+  void MemcpyAsync(void* dst, const void* src, size_t size, IoDirection dir) const;
+
+ private:
+  int device_;
+  plhip_ctx* ctx_{nullptr};
+  void* ws_{nullptr};
+  size_t ws_bytes_{0};
+};
+
 template <>
 class TargetWrapper<TARGET(kHIP)> {
  public:
@@ -51,6 +77,7 @@ class TargetWrapper<TARGET(kHIP)> {
   // Adopt an externally owned hipStream_t as this thread's execution stream for `device`.
   static void AdoptStream(int device, stream_t stream);
   static plhip_ctx* Ctx();  // this thread's context on the current device (created on first use)
+  static std::shared_ptr<HipExecState> State();  // ... and the state object that owns it
   static stream_t ExecStream();
   static void StreamSync();
   static void DeviceSync() { StreamSync(); }

@@ -125,7 +125,7 @@ void ConvCompute<Ptype, OutType>::PrepareForRun() {
   const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(param.filter, &staged, w_bytes));
   if (is_depthwise_) {
     void* d = weights_.mutable_data(TARGET(kHIP), w_bytes);
-    TargetWrapperHip::MemcpySync(d, w_dev, w_bytes, IoDirection::DtoD);
+    ctx.MemcpySync(d, w_dev, w_bytes, IoDirection::DtoD);
     kernel_func_name_ = std::string("conv_depthwise_") + std::to_string(desc_.kh) + "x" + std::to_string(desc_.kw) +
                         (kInt8Out ? "_int8_int8_hip" : "_int8_fp32_hip");
   } else {

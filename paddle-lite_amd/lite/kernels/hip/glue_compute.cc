@@ -46,7 +46,7 @@ class IoCopyHostToHipCompute : public KernelLite<TARGET(kHIP), PRECISION(kAny), 
     const size_t bytes = param.x->memory_size();
     void* d = param.y->mutable_data(TARGET(kHIP), bytes);
     param.y->set_precision(param.x->precision());
-    TargetWrapperHip::MemcpySync(d, param.x->raw_data(), bytes, IoDirection::HtoD);
+    this->ctx_->As<HIPContext>().MemcpySync(d, param.x->raw_data(), bytes, IoDirection::HtoD);
   }
 };
 
@@ -58,7 +58,8 @@ class IoCopyHipToHostCompute : public KernelLite<TARGET(kHIP), PRECISION(kAny), 
     const size_t bytes = param.x->memory_size();
     void* d = param.y->mutable_data(TARGET(kHost), bytes);
     param.y->set_precision(param.x->precision());
-    TargetWrapperHip::MemcpySync(d, param.x->raw_data(), bytes, IoDirection::DtoH);
+    // on the context's own stream: ordered behind the kernels that produce x, complete on return
+    this->ctx_->As<HIPContext>().MemcpySync(d, param.x->raw_data(), bytes, IoDirection::DtoH);
   }
 };
 

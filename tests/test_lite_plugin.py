@@ -222,3 +222,49 @@ def test_concurrent_predictors_reproduce_the_serial_result(lite, wl, plref):
         t.join()
     assert not errs, errs[:5]
 
+
+
+@pytest.mark.gpu
+def test_predictor_keeps_its_stream_across_threads(lite, plref):
+    """The execution state (stream + workspace) belongs to the predictor, not to the calling thread: built on one
+    thread, run on another, read back on a third — same bytes (lite/backends/cuda/context.h keeps the stream in the
+    context object; round 1 kept it in thread_local state and silently switched streams)."""
+    import threading
+    rng = np.random.default_rng(210)
+    x = rng.integers(-127, 128, (4, 32, 28, 28)).astype(np.int8)
+    w = rng.integers(-127, 128, (64, 32, 3, 3)).astype(np.int8)
+    bias = rng.uniform(-1, 1, 64).astype(np.float32)
+    ws = ((1 + np.arange(64) % 7) / 127.0 / 4.0).astype(np.float32)
+    box, errs = {}, []
+
+    def build():
+        try:
+            p = lite.Predictor(0)
+            p.add_feed("x", x.shape, lite.PREC_INT8)
+            p.add_io_copy("x", "xd", True)
+            p.add_conv("conv2d", "xd", "yd", w, bias, (1, 1), (1, 1, 1, 1), (1, 1), 1, 1, 0.0, 1 / 127.0, ws, 288 / 127.0, True)
+            p.add_io_copy("yd", "y", False)
+            p.set_input("x", x)
+            box["p"] = p
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    def run():
+        try:
+            for _ in range(3):
+                box["p"].run()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    for fn in (build, run):
+        t = threading.Thread(target=fn)
+        t.start()
+        t.join()
+    assert not errs, errs
+    try:
+        y = box["p"].get_var("y", np.int8)
+        sh = plref.shape(4, 32, 28, 28, 64, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)
+        y_ref, _ = plref.conv2d(sh, x, w, bias, 1 / 127.0, ws, 288 / 127.0, 1, 0.0, True)
+        assert np.array_equal(y, y_ref)
+    finally:
+        box["p"].close()
