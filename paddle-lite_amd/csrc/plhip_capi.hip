@@ -658,7 +658,14 @@ plhip_status plhip_selftest(plhip_ctx* ctx) {
 }  // extern "C"
 
 // Diagnostic only (not part of include/plhip.h): timeline stamps of the last PLHIP_GEMM_DEBUG=32 GEMM launch.
-namespace plhip { int debug_read_stamps(void* dst, size_t bytes); }
+namespace plhip {
+int debug_read_stamps(void* dst, size_t bytes);
+int debug_read_tr_stamps(void* dst, size_t bytes);
+}
+extern "C" int plhip_debug_read_tr_stamps(void* dst_host, size_t bytes) {
+  (void)hipDeviceSynchronize();
+  return plhip::debug_read_tr_stamps(dst_host, bytes);
+}
 extern "C" int plhip_debug_read_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();
   return plhip::debug_read_stamps(dst_host, bytes);

@@ -6,6 +6,7 @@
 
 #include "lite/api/graph_builder.h"
 #include "lite/api/hip_predictor.h"
+#include "lite/core/profile/timer.h"
 
 using paddle::lite::HipPredictor;
 using paddle::lite::Tensor;
@@ -252,6 +253,29 @@ int pllite_copy_var_to_device(pllite_predictor* p, const char* name, void* dst_d
     CHECK(t->target() == TARGET(kHIP)) << name << " is not device resident";
     CHECK_EQ(static_cast<int64_t>(t->memory_size()), bytes);
     p->pred.state()->MemcpyAsync(dst_dev, t->raw_data(), static_cast<size_t>(bytes), paddle::lite::IoDirection::DtoD);
+  });
+}
+int pllite_time_instruction(pllite_predictor* p, int index, int reps, float* avg_ms, float* min_ms, char* func_name, int cap) {
+  return guarded([&] {
+    auto& insts = p->pred.program().instructions();
+    CHECK(index >= 0 && index < static_cast<int>(insts.size())) << "instruction index out of range";
+    CHECK_GT(reps, 0);
+    auto& inst = insts[index];
+    paddle::lite::profile::DeviceTimer<paddle::lite::TargetType::kHIP> timer;
+    inst.Run();  // PrepareForRun / warm-up outside the laps
+    for (int r = 0; r < reps; ++r) {
+      timer.Start(inst.kernel()->mutable_context());
+      inst.Run();
+      timer.Stop(inst.kernel()->mutable_context());
+    }
+    if (avg_ms) *avg_ms = timer.LapTimes().Avg();
+    if (min_ms) *min_ms = timer.LapTimes().Min();
+    paddle::lite::profile::OpCharacter ch;
+    inst.kernel()->SetProfileRuntimeKernelInfo(&ch);
+    if (func_name && cap > 0) {
+      std::strncpy(func_name, ch.kernel_func_name.c_str(), static_cast<size_t>(cap) - 1);
+      func_name[cap - 1] = 0;
+    }
   });
 }
 int pllite_kernel_names(pllite_predictor* p, char* buf, int cap) {

@@ -73,6 +73,10 @@ int pllite_get_var(pllite_predictor* p, const char* name, void* host, int64_t ca
 void* pllite_var_device_ptr(pllite_predictor* p, const char* name);
 /* Asynchronous device-to-device copy of a device-resident variable into caller memory, on the predictor's stream. */
 int pllite_copy_var_to_device(pllite_predictor* p, const char* name, void* dst_dev, int64_t bytes);
+/* Times instruction `index` with profile::DeviceTimer<TargetType::kHIP> (lite/core/profile/timer.h): `reps` laps of
+ * one launch each after one untimed launch; returns the average / minimum lap in ms and the kernel_func_name the kernel
+ * reports through SetProfileRuntimeKernelInfo (lite/core/kernel.h:66-72). */
+int pllite_time_instruction(pllite_predictor* p, int index, int reps, float* avg_ms, float* min_ms, char* func_name, int cap);
 /* '\n'-separated "op:target/precision/layout/alias -> kernel_func_name" list of the program. */
 int pllite_kernel_names(pllite_predictor* p, char* buf, int cap);
 

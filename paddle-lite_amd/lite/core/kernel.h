@@ -6,6 +6,7 @@
 #include <string>
 
 #include "lite/core/context.h"
+#include "lite/core/profile/profiler.h"
 #include "lite/core/type_system.h"
 #include "lite/utils/any.h"
 
@@ -49,8 +50,14 @@ class KernelBase {
   virtual PrecisionType precision() const = 0;
   virtual DataLayoutType layout() const = 0;
   virtual std::string name() const = 0;
-  // LITE_WITH_PROFILE's SetProfileRuntimeKernelInfo -> kernel_func_name (conv_gemmlike.cc:384)
-  virtual std::string kernel_func_name() const { return "NotImpl"; }
+  // lite/core/kernel.h:66-72 (LITE_WITH_PROFILE): the kernel names the device function it dispatches to, e.g.
+  // GemmLikeConv sets "conv_im2col_gemm_int8" (conv_gemmlike.cc:393-394, 441-459)
+  virtual void SetProfileRuntimeKernelInfo(paddle::lite::profile::OpCharacter* ch) { ch->kernel_func_name = std::string("NotImpl"); }
+  std::string kernel_func_name() {  // convenience over the hook above
+    profile::OpCharacter ch;
+    SetProfileRuntimeKernelInfo(&ch);
+    return ch.kernel_func_name;
+  }
 
   const Type* GetInputDeclType(const std::string& arg) const {
     auto* r = ParamTypeRegistry::Global().Retrieve(key_with_alias(), place());

@@ -21,7 +21,7 @@ class ConvCompute : public KernelLite<TARGET(kHIP), Ptype> {
   void PrepareForRun() override;
   void ReInitWhenNeeded() override;
   void Run() override;
-  std::string kernel_func_name() const override { return kernel_func_name_; }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = kernel_func_name_; }
   ~ConvCompute() override = default;
 
  private:

@@ -95,7 +95,9 @@ class FcCompute : public KernelLite<TARGET(kHIP), Ptype> {
                                       (relu_ ? 1 : 0) | (gemm_route ? 2 : 0), y, kind));
   }
   // the library picks the MFMA kernel when k % 32 == 0 (csrc/misc_ops.hip launch_fc), the dot4 kernels otherwise
-  std::string kernel_func_name() const override { return (k_ % 32 == 0) ? "fc_int8_mfma32x32x32_hip" : "fc_int8_dot4_hip"; }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override {
+    ch->kernel_func_name = (k_ % 32 == 0) ? "fc_int8_mfma32x32x32_hip" : "fc_int8_dot4_hip";
+  }
 
  private:
   DDim last_shape_;

@@ -23,6 +23,7 @@ class CalibComputeFp32ToInt8 : public KernelLite<TARGET(kHIP), PRECISION(kInt8)>
                                               param.output->mutable_data<int8_t>(TARGET(kHIP)), param.scale,
                                               param.input->numel()));
   }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = "fp32_to_int8_hip"; }
 };
 
 class CalibComputeInt8ToFp32 : public KernelLite<TARGET(kHIP), PRECISION(kInt8)> {
@@ -35,6 +36,7 @@ class CalibComputeInt8ToFp32 : public KernelLite<TARGET(kHIP), PRECISION(kInt8)>
                                               param.output->mutable_data<float>(TARGET(kHIP)), param.scale,
                                               param.input->numel()));
   }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = "int8_to_fp32_hip"; }
 };
 
 // precision/layout kAny like the CUDA io_copy kernels: bytes are moved, whatever they mean.
@@ -48,6 +50,7 @@ class IoCopyHostToHipCompute : public KernelLite<TARGET(kHIP), PRECISION(kAny), 
     param.y->set_precision(param.x->precision());
     this->ctx_->As<HIPContext>().MemcpySync(d, param.x->raw_data(), bytes, IoDirection::HtoD);
   }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = "io_copy_host_to_hip"; }
 };
 
 class IoCopyHipToHostCompute : public KernelLite<TARGET(kHIP), PRECISION(kAny), DATALAYOUT(kAny)> {
@@ -61,6 +64,7 @@ class IoCopyHipToHostCompute : public KernelLite<TARGET(kHIP), PRECISION(kAny), 
     // on the context's own stream: ordered behind the kernels that produce x, complete on return
     this->ctx_->As<HIPContext>().MemcpySync(d, param.x->raw_data(), bytes, IoDirection::DtoH);
   }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = "io_copy_hip_to_host"; }
 };
 
 class PoolCompute : public KernelLite<TARGET(kHIP), PRECISION(kFloat)> {
@@ -101,7 +105,7 @@ class PoolCompute : public KernelLite<TARGET(kHIP), PRECISION(kFloat)> {
                         std::to_string(pd.stride[0]) + "_" + param.pooling_type + "_hip";
     HIP_CALL(ctx.ctx(), plhip_pool2d_f32(ctx.ctx(), &pd, x, y));
   }
-  std::string kernel_func_name() const override { return kernel_func_name_; }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = kernel_func_name_; }
 
  private:
   std::string kernel_func_name_{"pooling_hip"};
@@ -118,7 +122,7 @@ class ElementwiseAddCompute : public KernelLite<TARGET(kHIP), PRECISION(kFloat)>
     HIP_CALL(ctx.ctx(), plhip_elementwise_add_f32(ctx.ctx(), param.X->data<float>(), param.Y->data<float>(),
                                                   param.Out->mutable_data<float>(TARGET(kHIP)), param.X->numel(), 0));
   }
-  std::string kernel_func_name() const override { return "elementwise_add_hip"; }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = "elementwise_add_hip"; }
 };
 
 // fusion_elementwise_add_activation, act_type relu (elementwise_compute.cc:192-207)
@@ -133,7 +137,7 @@ class ElementwiseAddActivationCompute : public KernelLite<TARGET(kHIP), PRECISIO
     HIP_CALL(ctx.ctx(), plhip_elementwise_add_f32(ctx.ctx(), param.X->data<float>(), param.Y->data<float>(),
                                                   param.Out->mutable_data<float>(TARGET(kHIP)), param.X->numel(), 1));
   }
-  std::string kernel_func_name() const override { return "elementwise_add_relu_hip"; }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = "elementwise_add_relu_hip"; }
 };
 
 class SoftmaxCompute : public KernelLite<TARGET(kHIP), PRECISION(kFloat)> {
@@ -148,6 +152,7 @@ class SoftmaxCompute : public KernelLite<TARGET(kHIP), PRECISION(kFloat)> {
     HIP_CALL(ctx.ctx(), plhip_softmax_f32(ctx.ctx(), param.x->data<float>(), static_cast<int>(d.count(0, axis)),
                                           static_cast<int>(d[axis]), param.output->mutable_data<float>(TARGET(kHIP))));
   }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = "softmax_inner1_hip"; }
 };
 
 }  // namespace hip

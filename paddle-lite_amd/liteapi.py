@@ -63,6 +63,7 @@ def load():
     L.pllite_var_device_ptr.argtypes = [vp, cs]
     L.pllite_var_device_ptr.restype = vp
     L.pllite_kernel_names.argtypes = [vp, cs, i32]
+    L.pllite_time_instruction.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(f32), cs, i32]
     L.pllite_copy_var_to_device.argtypes = [vp, cs, vp, i64]
     _lib = L
     return L
@@ -230,6 +231,13 @@ class Predictor:
 
     def copy_var_to_device(self, name, dst_ptr, nbytes):
         self._ck(self.L.pllite_copy_var_to_device(self.h, name.encode(), C.c_void_p(dst_ptr), nbytes))
+
+    def time_instruction(self, index, reps=10):
+        """(avg_ms, min_ms, kernel_func_name) of one instruction, timed with DeviceTimer<kHIP> (lite/core/profile/timer.h)."""
+        a, m = C.c_float(), C.c_float()
+        buf = C.create_string_buffer(256)
+        self._ck(self.L.pllite_time_instruction(self.h, index, reps, C.byref(a), C.byref(m), buf, len(buf)))
+        return a.value, m.value, buf.value.decode()
 
     def kernel_names(self):
         buf = C.create_string_buffer(1 << 16)

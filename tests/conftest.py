@@ -6,6 +6,9 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the oracle's OpenMP team: the cores this process may use, not every core of the host (a GPU box exposes a 16-core share
+# of a large machine; 256 threads on it made one oracle graph at batch 128 take 220 s)
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0))))))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

@@ -268,3 +268,31 @@ def test_predictor_keeps_its_stream_across_threads(lite, plref):
         assert np.array_equal(y, y_ref)
     finally:
         box["p"].close()
+
+
+@pytest.mark.gpu
+def test_device_timer_and_kernel_func_name(lite):
+    """profile::DeviceTimer<TargetType::kHIP> (hipEvents on the context's stream, member set of timer.h:123-158) times a
+    conv launch, and the kernel reports its device function through SetProfileRuntimeKernelInfo like
+    conv_gemmlike.cc:384 does ("conv_im2col_gemm_int8")."""
+    rng = np.random.default_rng(220)
+    x = rng.integers(-127, 128, (32, 64, 56, 56)).astype(np.int8)
+    w = rng.integers(-127, 128, (128, 64, 3, 3)).astype(np.int8)
+    p = lite.Predictor(0)
+    try:
+        p.add_feed("x", x.shape, lite.PREC_INT8)
+        p.add_io_copy("x", "xd", True)
+        p.add_conv("conv2d", "xd", "yd", w, None, (1, 1), (1, 1, 1, 1), (1, 1), 1, 1, 0.0, 1 / 127.0, np.full(128, 1 / 127.0, np.float32),
+                   576 / 127.0, True)
+        p.add_calib("yd", "yf", 576 / 127.0, False)
+        p.set_input("x", x)
+        p.run()
+        avg, mn, name = p.time_instruction(1, reps=20)
+        assert name.startswith("conv_") and "gemm_int8" in name
+        # 14.8 GOP: between the MFMA roof (3 us) and a generous upper bound; min <= avg; laps are real device time
+        assert 0.002 < mn <= avg < 5.0
+        _, _, cname = p.time_instruction(2, reps=2)
+        assert cname == "int8_to_fp32_hip"
+        assert p.time_instruction(0, reps=1)[2] == "io_copy_host_to_hip"
+    finally:
+        p.close()

@@ -25,7 +25,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("layer", nargs="?", default="pw8")
     ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--tr", action="store_true", help="the transposed-read ring kernel (gemm_tr_i8.hip): 8 waves per block")
     args = ap.parse_args()
+    WPB = 8 if args.tr else 4
     assert int(os.environ.get("PLHIP_GEMM_DEBUG", "0")) & 32, "run with PLHIP_GEMM_DEBUG=32 (or 33, 34 ...)"
     rng = np.random.default_rng(0)
     B = args.batch
@@ -49,11 +51,12 @@ def main():
             ctx.sync()
             hwp = (ho * ho + 15) // 16 * 16
             nblk = min(1024, ((cout + 255) // 256) * ((B * hwp + 127) // 128 + 7) // 8 * 8)
-            buf = np.zeros(1024 * 4 * SLOTS, np.uint64)
-            L.plhip_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
-            rc = L.plhip_debug_read_stamps(buf.ctypes.data, buf.nbytes)
+            buf = np.zeros(1024 * WPB * SLOTS, np.uint64)
+            rd = L.plhip_debug_read_tr_stamps if args.tr else L.plhip_debug_read_stamps
+            rd.argtypes = [C.c_void_p, C.c_size_t]
+            rc = rd(buf.ctypes.data, buf.nbytes)
             assert rc == 0, rc
-            st = buf.reshape(1024, 4, SLOTS)[:nblk].astype(np.int64)
+            st = buf.reshape(1024, WPB, SLOTS)[:nblk].astype(np.int64)
             live = st[:, :, 1] != 0
             st = st[live[:, 0]]
             print("blocks with stamps:", st.shape[0], "of", nblk)
@@ -74,10 +77,24 @@ def main():
 
             show("entry -> prologue issued", t[:, 3] - t[:, 1])
             show("prologue -> loop top (first data)", t[:, 4] - t[:, 3])
-            for i in range(min(ks, SLOTS - 8) - 1):
-                show("K-step %d" % i, t[:, 5 + i] - t[:, 4 + i])
-            lastk = 4 + min(ks, SLOTS - 8) - 1
-            if int(os.environ.get("PLHIP_GEMM_DEBUG", "0")) & 64:
+            if args.tr:
+                nk = min(ks, SLOTS - 9)
+                show("loop top -> K-step 0 top (first reads)", t[:, 5] - t[:, 4])
+                for i in range(nk - 1):
+                    show("K-step %d" % i, t[:, 6 + i] - t[:, 5 + i])
+                lastk = 5 + nk - 1
+            else:
+                for i in range(min(ks, SLOTS - 8) - 1):
+                    show("K-step %d" % i, t[:, 5 + i] - t[:, 4 + i])
+                lastk = 4 + min(ks, SLOTS - 8) - 1
+            if args.tr and int(os.environ.get("PLHIP_GEMM_DEBUG", "0")) & 64:
+                show("  K-step 6: top -> vmcnt wait done", t[:, 22] - t[:, 11])
+                show("  K-step 6: barrier", t[:, 23] - t[:, 22])
+                show("  K-step 6: 10 LDS reads issued", t[:, 24] - t[:, 23])
+                show("  K-step 6: DMA pieces issued", t[:, 25] - t[:, 24])
+                show("  K-step 6: 8 MFMAs issued", t[:, 21] - t[:, 25])
+                show("  K-step 6: -> next top (lgkmcnt wait)", t[:, 12] - t[:, 21])
+            elif int(os.environ.get("PLHIP_GEMM_DEBUG", "0")) & 64:
                 show("  K-step 6: top -> vmcnt wait done", t[:, 20] - t[:, 10])
                 show("  K-step 6: barrier", t[:, 21] - t[:, 20])
                 show("  K-step 6: LDS reads issued + returned", t[:, 22] - t[:, 21])
@@ -85,6 +102,10 @@ def main():
                 show("  K-step 6: end -> next top", t[:, 11] - t[:, 23])
             show("last K-step -> loop end", t[:, SLOTS - 4] - t[:, lastk])
             show("whole loop", t[:, SLOTS - 4] - t[:, 4])
+            if args.tr:
+                show("  loop end -> barrier passed", t[:, SLOTS - 6] - t[:, SLOTS - 4])
+                show("  requantise + stage in LDS", t[:, SLOTS - 5] - t[:, SLOTS - 6])
+                show("  read back + global stores issued", t[:, SLOTS - 3] - t[:, SLOTS - 5])
             show("epilogue issue", t[:, SLOTS - 3] - t[:, SLOTS - 4])
             show("store drain (vmcnt 0)", t[:, SLOTS - 2] - t[:, SLOTS - 3])
             show("wave total", t[:, SLOTS - 2] - t[:, 1])
