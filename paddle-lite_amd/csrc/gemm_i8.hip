@@ -979,7 +979,7 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
   g.dbg = dbg_env;
   // MFMA-heavy shapes: the transposed-read ring kernel (gemm_tr_i8.hip).  It moves END-aligned 16-byte pieces and must
   // know the TRUE row length of a dense slab (HW = 49: the dword kernels get it rounded up to 4).
-  if (g.M > 32 && gemm_variant() == 0 && (dbg_env & ~32) == 0) {
+  if (g.M > 32 && (gemm_variant() == 0 || g.im_kw > 0) && (dbg_env & ~96) == 0) {
     GemmArgs t = g;
     if (t.im_kw == 0 && t.XP > 0 && t.XP < t.HWX) t.HWX = t.XP;
     if (launch_gemm_tr(t, out, s)) return;

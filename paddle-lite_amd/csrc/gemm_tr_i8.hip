@@ -172,7 +172,10 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
   // ---- column space (gemm_i8_dma_kernel): every image's HWX columns padded to HWP = roundup(HWX, 16); the last
   // 16-byte chunk of an image is END-aligned (source columns HWX-16 .. HWX-1), its leading 16 - HWX%16 columns are
   // duplicates that are never stored
-  const int HWP = (g.HWX + 15) & ~15, full16 = g.HWX & ~15, rem16 = g.HWX & 15;
+  // Rows shorter than 16 columns (implicit GEMM on 14x14 / 7x7 planes: an "image" is one output row): ONE start-aligned
+  // chunk per row, its trailing 16 - HWX columns are garbage (bytes of the next padded row) and are never stored.
+  const bool short_rows = g.HWX < 16;  // block-uniform
+  const int HWP = (g.HWX + 15) & ~15, full16 = short_rows ? 16 : (g.HWX & ~15), rem16 = short_rows ? 0 : (g.HWX & 15);
   const int CPI = HWP >> 4;  // 16-column chunks per image
 
   // ---- this lane's scale / bias: ordinary loads FIRST and alone (next to LDS-DMA the compiler can only wait for an
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
     int pb = J / CPI;
     int pj = (J - pb * CPI) << 4;
     if (pb >= g.NB) { pb = 0; pj = 0; }
-    const int pcol = pj < full16 ? pj : g.HWX - 16;
+    const int pcol = pj < full16 ? pj : g.HWX - 16;  // short rows: full16 = 16, pj = 0
     const uint8_t* asrc;
     if (implicit) {
       const int bi_ = pb / g.im_oh, oh = pb - bi_ * g.im_oh;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
     const bool cvalid = b < g.NB;
     const int hw0 = pj < full16 ? pj : g.HWX - 16;
     const int skip = pj < full16 ? 0 : 16 - rem16;
-    const int room = implicit ? 16 : g.HWY - hw0;  // output columns left in the row from the chunk's first column
+    const int room = short_rows ? g.HWX : (implicit ? 16 : g.HWY - hw0);  // output columns left in the row from the chunk's first column
     int hw = hw0;
     if (implicit) {
       const int bi_ = b / g.im_oh;
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
         const bool cvalid = b < g.NB;
         const int hw0 = pj < full16 ? pj : g.HWX - 16;
         const int skip = pj < full16 ? 0 : 16 - rem16;
-        const int room = implicit ? 16 : g.HWY - hw0;
+        const int room = short_rows ? g.HWX : (implicit ? 16 : g.HWY - hw0);
         int hwb = hw0;
         if (implicit) {
           const int bi_ = b / g.im_oh;
@@ -484,7 +487,7 @@ int debug_read_tr_stamps(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tr_stamps), bytes, 0, hipMemcpyDeviceToHost);
 }
 
-static int tr_enabled() {  // PLHIP_GEMM_TR=0: A/B runs against the first-generation kernels
+int gemm_tr_enabled() {  // PLHIP_GEMM_TR=0: first-generation kernels only (A/B runs)
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("PLHIP_GEMM_TR");
@@ -529,7 +532,8 @@ bool launch_gemm_tr(const GemmArgs& g_in, int out, hipStream_t s) {
     }
     g.dbg = (g.dbg & 0xff) | (delay_env << 8);
   }
-  if (!tr_enabled() || g.KS < 4 || g.HWX < 16) return false;
+  // rows shorter than 16 bytes: only on the padded copy of the implicit route (a 16-byte piece may run past the row)
+  if (!gemm_tr_enabled() || g.KS < 4 || (g.HWX < 16 && g.im_kw == 0)) return false;
   if ((long)g.NB * ((g.HWX + 15) & ~15) >= ((long)1 << 31) - 1024) return false;
 #define PLHIP_TR_OUT(WN_, WM_)                                          \
   do {                                                                  \

@@ -102,13 +102,18 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   // 128 with K >= 256) skip the im2col buffer: implicit GEMM on a zero-padded copy of the input (1.08x the input
   // instead of kh*kw x: BASELINE config #2 spent 128 of 149 us writing its 57.8 MB im2col buffer)
   if (g->impl == IMPL_IM2COL_GEMM && d->groups == 1 && d->stride[0] == 1 && d->stride[1] == 1 && d->dil[0] == 1 &&
-      d->dil[1] == 1 && g->ow >= 16 && d->kw <= 11 && d->kh * d->kw <= 121 && !implicit_gemm_disabled()) {
-    const int ma = (g->MA == 2 && g->Mg <= 128 && g->Mg > 64) ? 1 : g->MA;  // launch_gemm_i8's tile choice
-    const int mt = cdiv(g->Mg, 32 * ma);
+      d->dil[1] == 1 && d->kw <= 11 && d->kh * d->kw <= 121 && !implicit_gemm_disabled()) {
     const size_t padded = (size_t)d->n * d->cin * (d->h + d->pad[0] + d->pad[1]) * (d->w + d->pad[2] + d->pad[3]);
-    if (mt >= 4 && g->KS >= 4 && (ma == 2 || g->KS >= 8) && padded < ((size_t)1 << 31) - 4096 &&
-        (size_t)d->n * g->oh * rup(g->ow, 16) < ((size_t)1 << 31) - 256)
-      g->impl = IMPL_IMPLICIT_GEMM;
+    const bool fits = padded < ((size_t)1 << 31) - 4096 && (size_t)d->n * g->oh * rup(g->ow, 16) < ((size_t)1 << 31) - 256;
+    if (plhip::gemm_tr_enabled()) {
+      // transposed-read ring kernel: any M > 32, K >= 97, and output rows down to 7 columns (one start-aligned 16-byte
+      // chunk per row; 14x14 and 7x7 planes of ResNet50's last stages)
+      if (fits && g->Mg > 32 && g->KS >= 4 && g->ow >= 7) g->impl = IMPL_IMPLICIT_GEMM;
+    } else {
+      const int ma = (g->MA == 2 && g->Mg <= 128 && g->Mg > 64) ? 1 : g->MA;  // launch_gemm_i8's tile choice
+      const int mt = cdiv(g->Mg, 32 * ma);
+      if (fits && g->ow >= 16 && mt >= 4 && g->KS >= 4 && (ma == 2 || g->KS >= 8)) g->impl = IMPL_IMPLICIT_GEMM;
+    }
   }
   return true;
 }

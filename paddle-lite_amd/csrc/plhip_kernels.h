@@ -85,6 +85,7 @@ void launch_fused_dwpw(const FusedArgs& a, int out, hipStream_t s);
 void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);
 // second-generation ring kernel (gemm_tr_i8.hip); false = shape outside it, the caller falls back
 bool launch_gemm_tr(const GemmArgs& g, int out, hipStream_t s);
+int gemm_tr_enabled();
 void launch_pack_weights(const int8_t* w, int8_t* wp, int G, int Mg, int Kg, int MT32, int KS, hipStream_t s);
 void launch_im2col(const Im2colArgs& a, hipStream_t s);
 int launch_depthwise(const DwArgs& a, int out, hipStream_t s);  // returns 0 or -3 (unsupported LDS size)

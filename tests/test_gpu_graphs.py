@@ -213,3 +213,30 @@ def test_pointwise_7x7_rows_at_the_end_of_an_allocation(gpu_ctx, plref, pkg):
     acc = gpu_ctx.conv2d(d, x, w, None, None, capi.OUT_I32)
     s = plref.shape(n, cin, 7, 7, cout, 1, 1, (0, 0, 0, 0), (1, 1), (1, 1), 1)
     assert np.array_equal(acc, plref.conv2d_acc(s, x, w, via_gemm=True))
+
+
+def test_implicit_gemm_short_rows_and_small_m(gpu_ctx, plref, pkg):
+    """Dense 3x3 stride-1 convs take the implicit-GEMM route of the transposed-read ring kernel for any M > 32 and for
+    output rows down to 7 columns (one start-aligned 16-byte chunk per row whose trailing columns are garbage and must
+    never be stored): ResNet50's 56x56 M = 64, 14x14 and 7x7 layers.  int32 accumulators, int8 and fp32 outputs."""
+    capi = pkg.capi
+    rng = np.random.default_rng(330)
+    for (n, cin, cout, hw, k, pad) in [(3, 32, 48, 14, 3, 1), (2, 16, 64, 7, 3, 1), (2, 24, 40, 9, 3, 1), (1, 16, 96, 15, 3, 1),
+                                       (2, 12, 64, 11, 5, 2), (2, 64, 64, 56, 3, 1)]:
+        x = rng.integers(-127, 128, (n, cin, hw, hw)).astype(np.int8)
+        w = rng.integers(-127, 128, (cout, cin, k, k)).astype(np.int8)
+        bias = rng.uniform(-1, 1, cout).astype(np.float32)
+        wsc = ((1 + np.arange(cout) % 7) / 127.0 / 4.0).astype(np.float32)
+        d = capi.conv_desc(n, cin, hw, hw, cout, k, k, (pad,) * 4, (1, 1), (1, 1), 1, capi.ACT_RELU, 0.0)
+        assert capi.load().plhip_conv_impl_name(d).decode().startswith("conv_implicit_gemm"), (cin, cout, hw)
+        s = plref.shape(n, cin, hw, hw, cout, k, k, (pad,) * 4, (1, 1), (1, 1), 1)
+        acc_ref = plref.conv2d_acc(s, x, w)
+        assert np.array_equal(gpu_ctx.conv2d(d, x, w, None, None, capi.OUT_I32), acc_ref), (cin, cout, hw)
+        for int8_out, kind in ((1, capi.OUT_I8), (0, capi.OUT_F32)):
+            sc, bi, al = plref.fold_scales(int8_out, 1 / 127.0, wsc, cin * k * k / 127.0, bias, cout, 1, 0.0)
+            y = gpu_ctx.conv2d(d, x, w, sc, bi, kind)
+            ref = plref.epilogue(acc_ref, sc, bi, 1, al, bool(int8_out))
+            if int8_out:
+                assert np.array_equal(y, ref), (cin, cout, hw)
+            else:
+                np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6)

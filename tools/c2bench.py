@@ -24,8 +24,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--n", type=int, default=32)
+    ap.add_argument("--cin", type=int, default=64)
+    ap.add_argument("--cout", type=int, default=128)
+    ap.add_argument("--hw", type=int, default=56)
     a = ap.parse_args()
-    n, cin, hw, cout = a.n, 64, 56, 128
+    n, cin, hw, cout = a.n, a.cin, a.hw, a.cout
     rng = np.random.default_rng(0)
     with capi.Context(0) as ctx:
         L = ctx.L
@@ -42,8 +45,8 @@ def main():
         for kind, name, esz in ((capi.OUT_I8, "int8 out", 1), (capi.OUT_I32, "int32 acc", 4)):
             dy = ctx.malloc(n * cout * hw * hw * esz)
             ms = time_op(ctx, lambda: ctx.check(L.plhip_conv2d_int8(ctx.h, C.byref(d), dx, dwp, ds, db, dy, kind, dws, wsb), "conv"), a.reps)
-            print("C2 %-9s %8.2f us  %7.1f TOP/s  %.1f %% of dense i8 MFMA peak  (workspace %.1f MB, %s)" % (
-                name, ms * 1e3, ops / ms / 1e9, 100 * ops / ms / 1e9 / PEAK, wsb / 1e6, L.plhip_conv_impl_name(C.byref(d)).decode()))
+            print("conv3x3 n%d %d->%d @%d %-9s %8.2f us  %7.1f TOP/s  %.1f %% of dense i8 MFMA peak  (workspace %.1f MB, %s)" % (
+                n, cin, cout, hw, name, ms * 1e3, ops / ms / 1e9, 100 * ops / ms / 1e9 / PEAK, wsb / 1e6, L.plhip_conv_impl_name(C.byref(d)).decode()))
 
 
 if __name__ == "__main__":
