@@ -102,6 +102,18 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
                                const void* w_packed, const float* scale, const float* bias, void* y,
                                plhip_out_kind out, void* workspace, size_t workspace_bytes);
 const char* plhip_conv_impl_name(const plhip_conv_desc* d);
+/* fp32-output conv with a fused graph tail (graph-level fusion on this target).  Replaces the
+ * instruction run  conv2d[fp32_out] -> elementwise_add | fusion_elementwise_add_activation(relu) -> calib[fp32_to_int8]
+ * of the reference's ResNet50 / MobileNetV2 programs (lite/kernels/arm/{conv,elementwise,calib}_compute.cc), any suffix
+ * of it:   v = act(fma(float(acc), scale, bias));   if (residual) v = v + residual[i];   if (residual_relu) v = max(v, 0);
+ *          if (y_f32) y_f32[i] = v;   if (y_i8) y_i8[i] = sat8(round_half_away(v * (1.f / calib_scale)))
+ * Every value is rounded exactly as the separate instructions round it, so the results are bit-identical to running
+ * them one by one.  residual / y_f32 / y_i8 have the output's NCHW shape; y_f32 may be NULL when only the int8 copy has
+ * consumers.  The field ConvParam::residualData of the reference (lite/operators/op_params.h:446-502) is the operand. */
+plhip_status plhip_conv2d_int8_fused(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x, const void* w_packed,
+                                     const float* scale, const float* bias, float* y_f32, const float* residual,
+                                     int residual_relu, int8_t* y_i8, float calib_scale, void* workspace,
+                                     size_t workspace_bytes);
 
 /* ---- depthwise conv (groups == cin == cout) ----
  * Replaces: DepthwiseConv<kInt8,*>::Run (lite/kernels/arm/conv_depthwise.cc:357-446) ->
@@ -166,6 +178,9 @@ typedef struct {
   int exclusive;  /* avg: divide by the clipped window size (pooling.cc:160-164) */
 } plhip_pool_desc;
 plhip_status plhip_pool2d_f32(plhip_ctx* ctx, const plhip_pool_desc* d, const float* x, float* y);
+/* int8 max pool: the kHIP graph fusion turns conv2d[fp32_out] -> pool2d(max) -> calib into conv+calib -> this (max
+ * commutes with the monotonic quantiser of type_trans.cc:183-184, so y == calib(pool2d_f32(x_f32))). */
+plhip_status plhip_pool2d_max_i8(plhip_ctx* ctx, const plhip_pool_desc* d, const int8_t* x, int8_t* y);
 /* elementwise_add / fusion_elementwise_add_activation(relu), same-shape operands: replaces ElementwiseAddCompute /
  * ElementwiseAddActivationCompute (lite/kernels/arm/elementwise_compute.cc:85-140) -> elementwise_add{,_relu}<float>
  * (lite/backends/arm/math/elementwise.cc).  out may alias x or y. */

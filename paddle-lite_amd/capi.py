@@ -22,10 +22,10 @@ EXPORTS = [
     "plhip_memcpy_d2h", "plhip_memcpy_d2d", "plhip_memset", "plhip_stream_sync", "plhip_event_create",
     "plhip_event_record", "plhip_event_elapsed_ms", "plhip_event_destroy",
     "plhip_conv_packed_weight_bytes", "plhip_pack_conv_weights", "plhip_conv_workspace_bytes",
-    "plhip_conv2d_int8", "plhip_conv_impl_name", "plhip_depthwise_conv_int8", "plhip_dwpw_fused_int8",
+    "plhip_conv2d_int8", "plhip_conv2d_int8_fused", "plhip_conv_impl_name", "plhip_depthwise_conv_int8", "plhip_dwpw_fused_int8",
     "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
     "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
-    "plhip_pool2d_f32", "plhip_elementwise_add_f32", "plhip_selftest",
+    "plhip_pool2d_f32", "plhip_pool2d_max_i8", "plhip_elementwise_add_f32", "plhip_selftest",
 ]
 
 
@@ -104,6 +104,7 @@ def load():
     L.plhip_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     L.plhip_conv_workspace_bytes.restype = sz
     L.plhip_conv2d_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, sz]
+    L.plhip_conv2d_int8_fused.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i32, vp, f32, vp, sz]
     L.plhip_conv_impl_name.argtypes = [C.POINTER(ConvDesc)]
     L.plhip_conv_impl_name.restype = C.c_char_p
     L.plhip_depthwise_conv_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32]
@@ -117,6 +118,7 @@ def load():
     L.plhip_global_avg_pool_f32.argtypes = [vp, vp, i32, i32, vp]
     L.plhip_softmax_f32.argtypes = [vp, vp, i32, i32, vp]
     L.plhip_pool2d_f32.argtypes = [vp, C.POINTER(PoolDesc), vp, vp]
+    L.plhip_pool2d_max_i8.argtypes = [vp, C.POINTER(PoolDesc), vp, vp]
     L.plhip_elementwise_add_f32.argtypes = [vp, vp, vp, vp, C.c_int64, i32]
     L.plhip_selftest.argtypes = [vp]
     _lib = L
@@ -210,6 +212,31 @@ class Context:
             self.free(p)
         return y
 
+    def conv2d_fused(self, d, x, w, scale, bias, residual, residual_relu, calib_scale, want_f32=True):
+        """plhip_conv2d_int8_fused on host arrays: returns (y_f32 or None, y_i8 or None)."""
+        oh, ow = out_hw(d)
+        shape = (d.n, d.cout, oh, ow)
+        dx = self.to_device(np.ascontiguousarray(x, np.int8))
+        dw = self.to_device(np.ascontiguousarray(w, np.int8))
+        ds = self.to_device(np.ascontiguousarray(scale, np.float32))
+        db = self.to_device(np.ascontiguousarray(bias, np.float32)) if bias is not None else C.c_void_p()
+        dr = self.to_device(np.ascontiguousarray(residual, np.float32)) if residual is not None else C.c_void_p()
+        n_out = int(np.prod(shape))
+        dyf = self.malloc(n_out * 4) if want_f32 else C.c_void_p()
+        dyq = self.malloc(n_out) if calib_scale is not None else C.c_void_p()
+        dwp = self.malloc(self.L.plhip_conv_packed_weight_bytes(C.byref(d)))
+        self.check(self.L.plhip_pack_conv_weights(self.h, C.byref(d), dw, dwp), "pack")
+        wsb = self.L.plhip_conv_workspace_bytes(C.byref(d))
+        dws = self.malloc(wsb) if wsb else C.c_void_p()
+        self.check(self.L.plhip_conv2d_int8_fused(self.h, C.byref(d), dx, dwp, ds, db, dyf, dr, int(residual_relu), dyq,
+                                                  float(calib_scale) if calib_scale is not None else 0.0, dws, wsb), "conv2d_fused")
+        yf = self.to_host(dyf, shape, np.float32) if want_f32 else None
+        yq = self.to_host(dyq, shape, np.int8) if calib_scale is not None else None
+        for p_ in [dx, dw, ds, dwp] + ([db] if bias is not None else []) + ([dr] if residual is not None else []) + \
+                ([dyf] if want_f32 else []) + ([dyq] if calib_scale is not None else []) + ([dws] if wsb else []):
+            self.free(p_)
+        return yf, yq
+
     def dwpw_fused(self, d_dw, x, w_dw, s_dw, b_dw, w_pw, s_pw, b_pw, pw_act, pw_alpha, out_kind):
         """Fused depthwise -> pointwise through the C ABI (host arrays in, host array out)."""
         oh, ow = out_hw(d_dw)
@@ -293,7 +320,8 @@ class Context:
 
     def pool2d(self, x, pooling_type, ksize, strides, pads, exclusive=True, ceil_mode=False):
         """x [n,c,h,w] fp32; pads {top, bottom, left, right}; output dims by PoolOutputSize (pool_op.cc:44-61)."""
-        x = np.ascontiguousarray(x, np.float32)
+        i8 = np.asarray(x).dtype == np.int8
+        x = np.ascontiguousarray(x, np.int8 if i8 else np.float32)
         n, c, h, w = x.shape
 
         def osz(i, k, p0, p1, s):
@@ -306,9 +334,10 @@ class Context:
         d.stride[:] = list(strides)
         d.is_max, d.exclusive = int(pooling_type == "max"), int(exclusive)
         dx = self.to_device(x)
-        dy = self.malloc(n * c * d.oh * d.ow * 4)
-        self.check(self.L.plhip_pool2d_f32(self.h, C.byref(d), dx, dy), "pool2d")
-        y = self.to_host(dy, (n, c, d.oh, d.ow), np.float32)
+        dy = self.malloc(n * c * d.oh * d.ow * (1 if i8 else 4))
+        fn = self.L.plhip_pool2d_max_i8 if i8 else self.L.plhip_pool2d_f32
+        self.check(fn(self.h, C.byref(d), dx, dy), "pool2d")
+        y = self.to_host(dy, (n, c, d.oh, d.ow), np.int8 if i8 else np.float32)
         self.free(dx), self.free(dy)
         return y
 

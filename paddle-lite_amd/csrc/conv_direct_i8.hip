@@ -252,6 +252,7 @@ __device__ __forceinline__ void stem_mfma_body(const DirectS2Args& a, const int8
   g.y_bstride = (size_t)a.cout * a.oh * a.ow;
   g.act = a.act;
   g.alpha = a.alpha;
+  g.res = nullptr; g.res_relu = 0; g.y2 = nullptr; g.inv_scale2 = 0.f;  // no fused graph tail on the stem
   const v4i af0 = *reinterpret_cast<const v4i*>(afrag + (size_t)lane * 16);
   if (OUT != OUT_I32) stage_scale_bias<1, OUT>(g, 0, lane, lsb);
 

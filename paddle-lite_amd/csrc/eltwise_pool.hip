@@ -72,6 +72,55 @@ __global__ __launch_bounds__(256) void pool2d_f32_kernel(PoolArgs a) {
   }
 }
 
+// int8 max pool (kHIP graph fusion: conv -> pool2d(max) -> calib becomes conv+calib -> THIS; max commutes with the
+// monotonic quantiser, so the bytes equal calib(pool(x))).  One lane = 4 consecutive outputs, packed into one dword.
+__global__ __launch_bounds__(256) void pool2d_max_i8_kernel(PoolArgs a) {
+  const int owq = (a.ow + 3) >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= owq * a.oh) return;
+  const int oy = idx / owq, oxq = idx - oy * owq;
+  const size_t plane = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
+  if (plane >= (size_t)a.planes) return;
+  const int8_t* __restrict__ xp = reinterpret_cast<const int8_t*>(a.x) + plane * (size_t)a.h * a.w;
+  int8_t* __restrict__ yp = reinterpret_cast<int8_t*>(a.y) + plane * (size_t)a.oh * a.ow + (size_t)oy * a.ow;
+  int sh = oy * a.sh - a.pt, eh = sh + a.kh;
+  sh = sh < 0 ? 0 : sh;
+  eh = eh > a.h ? a.h : eh;
+  int r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ox = oxq * 4 + j;
+    int sw = ox * a.sw - a.pl, ew = sw + a.kw;
+    sw = sw < 0 ? 0 : sw;
+    ew = ew > a.w ? a.w : ew;
+    int m = -128;
+    bool any = false;
+    if (ox < a.ow)
+      for (int y = sh; y < eh; ++y)
+        for (int x = sw; x < ew; ++x) {
+          const int v = xp[(size_t)y * a.w + x];
+          m = v > m ? v : m;
+          any = true;
+        }
+    r[j] = any ? m : 0;  // a window that covers padding only: 0, like pooling_basic
+  }
+  const int ox0 = oxq * 4;
+  if (ox0 + 3 < a.ow && (((uintptr_t)(yp + ox0)) & 3) == 0) {
+    *reinterpret_cast<uint32_t*>(yp + ox0) = pack4_i8(r[0], r[1], r[2], r[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ox0 + j < a.ow) yp[ox0 + j] = (int8_t)r[j];
+  }
+}
+
+void launch_pool2d_max_i8(const PoolArgs& a, hipStream_t s) {
+  const int owq = (a.ow + 3) >> 2;
+  const int gy = a.planes < 32768 ? a.planes : 32768;
+  dim3 grid((owq * a.oh + 255) / 256, gy, (a.planes + gy - 1) / gy);
+  hipLaunchKernelGGL(pool2d_max_i8_kernel, grid, dim3(256), 0, s, a);
+}
+
 void launch_pool2d(const PoolArgs& a, hipStream_t s) {
   const int owq = (a.ow + 3) >> 2;
   const int gy = a.planes < 32768 ? a.planes : 32768;

@@ -88,18 +88,52 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
             if (ACT == ACT_RELU6) f[i] = fminf(fmaxf(f[i], 0.f), g.alpha);
             if (ACT == ACT_LEAKY) f[i] = f[i] > 0.f ? f[i] : g.alpha * f[i];
           }
-          float* yp = reinterpret_cast<float*>(g.y) + yoff;
-          if (VEC_STORE) {
-            v4f v = {f[0], f[1], f[2], f[3]};
-            *reinterpret_cast<v4f*>(yp) = v;
-          } else if (hwy_room >= 4 && skip == 0) {
-            v4f v = {f[0], f[1], f[2], f[3]};
-            __builtin_memcpy(yp, &v, 16);
-          } else {
-            if (0 >= skip && 0 < hwy_room) yp[0] = f[0];
-            if (1 >= skip && 1 < hwy_room) yp[1] = f[1];
-            if (2 >= skip && 2 < hwy_room) yp[2] = f[2];
-            if (3 >= skip && 3 < hwy_room) yp[3] = f[3];
+          if (g.res) {  // fused residual add (+ relu): kernel-uniform
+            const float* rp = g.res + yoff;
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (VEC_STORE) {
+              const v4f rv = *reinterpret_cast<const v4f*>(rp);
+              r[0] = rv[0]; r[1] = rv[1]; r[2] = rv[2]; r[3] = rv[3];
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (i >= skip && i < hwy_room) r[i] = rp[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              f[i] = f[i] + r[i];
+              if (g.res_relu) f[i] = f[i] > 0.f ? f[i] : 0.f;
+            }
+          }
+          if (g.y) {
+            float* yp = reinterpret_cast<float*>(g.y) + yoff;
+            if (VEC_STORE) {
+              v4f v = {f[0], f[1], f[2], f[3]};
+              *reinterpret_cast<v4f*>(yp) = v;
+            } else if (hwy_room >= 4 && skip == 0) {
+              v4f v = {f[0], f[1], f[2], f[3]};
+              __builtin_memcpy(yp, &v, 16);
+            } else {
+              if (0 >= skip && 0 < hwy_room) yp[0] = f[0];
+              if (1 >= skip && 1 < hwy_room) yp[1] = f[1];
+              if (2 >= skip && 2 < hwy_room) yp[2] = f[2];
+              if (3 >= skip && 3 < hwy_room) yp[3] = f[3];
+            }
+          }
+          if (g.y2) {  // fused calib fp32 -> int8 of the value just produced
+            const uint32_t packed = pack4_i8(round_sat_i8(g.inv_scale2 * f[0]), round_sat_i8(g.inv_scale2 * f[1]),
+                                             round_sat_i8(g.inv_scale2 * f[2]), round_sat_i8(g.inv_scale2 * f[3]));
+            int8_t* qp = g.y2 + yoff;
+            if (VEC_STORE) {
+              *reinterpret_cast<uint32_t*>(qp) = packed;
+            } else if (hwy_room >= 4 && skip == 0) {
+              __builtin_memcpy(qp, &packed, 4);
+            } else {
+              if (0 >= skip && 0 < hwy_room) qp[0] = (int8_t)(packed & 0xff);
+              if (1 >= skip && 1 < hwy_room) qp[1] = (int8_t)((packed >> 8) & 0xff);
+              if (2 >= skip && 2 < hwy_room) qp[2] = (int8_t)((packed >> 16) & 0xff);
+              if (3 >= skip && 3 < hwy_room) qp[3] = (int8_t)(packed >> 24);
+            }
           }
         } else {
           const float s2 = sc[e], b2 = bi[e];  // staged already doubled for int8 output (store_scale_bias)

@@ -455,14 +455,47 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
               float f[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) f[e] = epilogue_f32(acc[t][u][4 * gq + e], sc[u], bi[u], g.act, g.alpha);
-              float* yp = reinterpret_cast<float*>(g.y) + yoff;
-              if (o >= skip && o + 3 < room) {
-                const v4f v = {f[0], f[1], f[2], f[3]};
-                __builtin_memcpy(yp, &v, 16);
-              } else {
+              const bool whole = o >= skip && o + 3 < room;
+              if (g.res) {  // fused residual add (+ relu): kernel-uniform
+                const float* rp = g.res + yoff;
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                if (whole) {
+                  v4f rv;
+                  __builtin_memcpy(&rv, rp, 16);
+                  r[0] = rv[0]; r[1] = rv[1]; r[2] = rv[2]; r[3] = rv[3];
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (o + e >= skip && o + e < room) yp[e] = f[e];
+                  for (int e = 0; e < 4; ++e)
+                    if (o + e >= skip && o + e < room) r[e] = rp[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  f[e] = f[e] + r[e];
+                  if (g.res_relu) f[e] = f[e] > 0.f ? f[e] : 0.f;
+                }
+              }
+              if (g.y) {
+                float* yp = reinterpret_cast<float*>(g.y) + yoff;
+                if (whole) {
+                  const v4f v = {f[0], f[1], f[2], f[3]};
+                  __builtin_memcpy(yp, &v, 16);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    if (o + e >= skip && o + e < room) yp[e] = f[e];
+                }
+              }
+              if (g.y2) {  // fused calib fp32 -> int8 of the value just produced (type_trans.cc:45,183-184)
+                const uint32_t packed = pack4_i8(round_sat_i8(g.inv_scale2 * f[0]), round_sat_i8(g.inv_scale2 * f[1]),
+                                                 round_sat_i8(g.inv_scale2 * f[2]), round_sat_i8(g.inv_scale2 * f[3]));
+                int8_t* qp = g.y2 + yoff;
+                if (whole) {
+                  __builtin_memcpy(qp, &packed, 4);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    if (o + e >= skip && o + e < room) qp[e] = (int8_t)(packed >> (8 * e));
+                }
               }
             }
           }

@@ -273,11 +273,19 @@ const char* plhip_conv_impl_name(const plhip_conv_desc* d) {
   return "conv_im2col_gemm_int8_mfma32x32x32";
 }
 
-plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x, const void* w_packed,
-                               const float* scale, const float* bias, void* y, plhip_out_kind out, void* workspace,
-                               size_t workspace_bytes) {
+struct ConvTail {  // fused graph tail of an fp32-output conv (plhip_conv2d_int8_fused)
+  const float* residual;
+  int residual_relu;
+  int8_t* y_i8;
+  float calib_scale;
+};
+
+static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x, const void* w_packed,
+                                const float* scale, const float* bias, void* y, plhip_out_kind out, void* workspace,
+                                size_t workspace_bytes, const ConvTail* tail) {
   ConvGeom g;
-  if (!ctx || !x || !w_packed || !y) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: null argument");
+  const bool y_opt = tail && tail->y_i8;  // the fp32 tensor itself may be dropped when only the int8 copy is consumed
+  if (!ctx || !x || !w_packed || (!y && !y_opt)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: null argument");
   if (!conv_geom(d, &g)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: bad conv descriptor");
   if (out != PLHIP_OUT_I32_ACC && out != PLHIP_OUT_F32 && out != PLHIP_OUT_I8)
     return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: bad out kind");
@@ -288,7 +296,13 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
       (size_t)d->cout * g.N >= ((size_t)1 << 31))
     return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_int8: tensor too large for 32-bit column index");
 
+  const float* t_res = tail ? tail->residual : nullptr;
+  const int t_relu = tail ? tail->residual_relu : 0;
+  int8_t* t_y2 = tail ? tail->y_i8 : nullptr;
+  const float t_inv = (tail && tail->y_i8) ? 1.f / tail->calib_scale : 0.f;  // type_trans.cc:45
+  const bool has_tail = t_res || t_y2;
   if (g.impl == IMPL_DIRECT_3X3S2) {
+    if (has_tail) return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_int8_fused: the direct 3x3 s2 stem has no fused tail");
     plhip::DirectS2Args a;
     a.x = x;
     a.wp = (const uint32_t*)w_packed;
@@ -336,7 +350,8 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     a.act = d->act;
     a.alpha = d->act_alpha;
     a.im_kw = d->kw; a.im_khkw = d->kh * d->kw; a.im_c = d->cin; a.im_ph = PH; a.im_pw = PW; a.im_oh = g.oh;
-    const bool vec_store_i = (g.ow & 3) == 0 && aligned(y, 4 * esz_i);
+    a.res = t_res; a.res_relu = t_relu; a.y2 = t_y2; a.inv_scale2 = t_inv;
+    const bool vec_store_i = (g.ow & 3) == 0 && aligned(y, 4 * esz_i) && aligned(t_res, 16) && aligned(t_y2, 4);
     plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store_i, true, ctx->stream);
     LAUNCHCHK(ctx, "gemm_i8_implicit");
     return PLHIP_OK;
@@ -385,12 +400,16 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     aligned_loads = true;
   }
   const size_t esz = out == PLHIP_OUT_I8 ? 1 : 4;
-  const bool vec_store = hwx == g.N && aligned(y, 4 * esz);
+  const bool vec_store = hwx == g.N && aligned(y, 4 * esz) && aligned(t_res, 16) && aligned(t_y2, 4);
   for (int grp = 0; grp < g.G; ++grp) {
     plhip::GemmArgs a;
     a.wp = (const int8_t*)w_packed + (size_t)grp * g.MT32 * g.KS * 1024;
     a.x = bmat + (size_t)grp * x_gstride;
-    a.y = (char*)y + (size_t)grp * g.Mg * g.N * esz;
+    a.y = y ? (char*)y + (size_t)grp * g.Mg * g.N * esz : nullptr;
+    a.res = t_res ? t_res + (size_t)grp * g.Mg * g.N : nullptr;
+    a.res_relu = t_relu;
+    a.y2 = t_y2 ? t_y2 + (size_t)grp * g.Mg * g.N : nullptr;
+    a.inv_scale2 = t_inv;
     a.scale = scale ? scale + (size_t)grp * g.Mg : nullptr;
     a.bias = bias ? bias + (size_t)grp * g.Mg : nullptr;
     a.M = g.Mg;
@@ -412,6 +431,23 @@ plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const i
     LAUNCHCHK(ctx, "gemm_i8");
   }
   return PLHIP_OK;
+}
+
+plhip_status plhip_conv2d_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x, const void* w_packed,
+                               const float* scale, const float* bias, void* y, plhip_out_kind out, void* workspace,
+                               size_t workspace_bytes) {
+  return conv2d_impl(ctx, d, x, w_packed, scale, bias, y, out, workspace, workspace_bytes, nullptr);
+}
+
+plhip_status plhip_conv2d_int8_fused(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x, const void* w_packed,
+                                     const float* scale, const float* bias, float* y_f32, const float* residual,
+                                     int residual_relu, int8_t* y_i8, float calib_scale, void* workspace,
+                                     size_t workspace_bytes) {
+  if (!y_f32 && !y_i8) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8_fused: no output");
+  if (y_i8 && !(calib_scale > 0.f)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8_fused: calib scale must be > 0");
+  if (residual_relu && !residual) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8_fused: residual_relu without a residual");
+  ConvTail t{residual, residual_relu, y_i8, calib_scale};
+  return conv2d_impl(ctx, d, x, w_packed, scale, bias, y_f32, PLHIP_OUT_F32, workspace, workspace_bytes, &t);
 }
 
 // ------------------------------------------------------------------ depthwise
@@ -588,7 +624,15 @@ plhip_status plhip_softmax_f32(plhip_ctx* ctx, const float* x, int rows, int col
   return PLHIP_OK;
 }
 
+static plhip_status pool2d_impl(plhip_ctx* ctx, const plhip_pool_desc* d, const void* x, void* y, bool i8);
 plhip_status plhip_pool2d_f32(plhip_ctx* ctx, const plhip_pool_desc* d, const float* x, float* y) {
+  return pool2d_impl(ctx, d, x, y, false);
+}
+plhip_status plhip_pool2d_max_i8(plhip_ctx* ctx, const plhip_pool_desc* d, const int8_t* x, int8_t* y) {
+  if (d && !d->is_max) return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_pool2d_max_i8: max pooling only (avg does not commute with the quantiser)");
+  return pool2d_impl(ctx, d, x, y, true);
+}
+static plhip_status pool2d_impl(plhip_ctx* ctx, const plhip_pool_desc* d, const void* x, void* y, bool i8) {
   if (!ctx || !d || !x || !y) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pool2d_f32: null argument");
   if (d->planes < 1 || d->h < 1 || d->w < 1 || d->oh < 1 || d->ow < 1 || d->kh < 1 || d->kw < 1 || d->stride[0] < 1 ||
       d->stride[1] < 1 || d->pad[0] < 0 || d->pad[1] < 0 || d->pad[2] < 0 || d->pad[3] < 0)
@@ -600,11 +644,12 @@ plhip_status plhip_pool2d_f32(plhip_ctx* ctx, const plhip_pool_desc* d, const fl
   if ((size_t)d->h * d->w >= ((size_t)1 << 31) || (size_t)d->oh * d->ow >= ((size_t)1 << 31))
     return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_pool2d_f32: plane too large");
   plhip::PoolArgs a;
-  a.x = x; a.y = y;
+  a.x = (const float*)x; a.y = (float*)y;
   a.planes = d->planes; a.h = d->h; a.w = d->w; a.oh = d->oh; a.ow = d->ow; a.kh = d->kh; a.kw = d->kw;
   a.sh = d->stride[0]; a.sw = d->stride[1]; a.pt = d->pad[0]; a.pb = d->pad[1]; a.pl = d->pad[2]; a.pr = d->pad[3];
   a.is_max = d->is_max ? 1 : 0; a.exclusive = d->exclusive ? 1 : 0;
-  plhip::launch_pool2d(a, ctx->stream);
+  if (i8) plhip::launch_pool2d_max_i8(a, ctx->stream);
+  else plhip::launch_pool2d(a, ctx->stream);
   LAUNCHCHK(ctx, "pool2d");
   return PLHIP_OK;
 }

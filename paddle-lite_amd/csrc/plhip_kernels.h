@@ -22,6 +22,15 @@ struct GemmArgs {
   int act;
   float alpha;
   int dbg;             // PLHIP_GEMM_DEBUG (timing experiments only): 1 = skip the epilogue, 2 = skip the K loop
+  // fused graph tail of an fp32-output conv (OUT_F32 only; all optional, zero = plain conv):
+  //   v = act(fma(acc, s, b));  if (res) v = v + res[same offset];  if (res_relu) v = max(v, 0);
+  //   if (y) y = v;  if (y2) y2 = round_sat_i8(v * inv_scale2)          (calib, type_trans.cc:45,183-184)
+  // i.e. conv2d[fp32_out] -> elementwise_add / fusion_elementwise_add_activation -> calib of the reference program
+  // in one launch, every value rounded exactly as the three instructions round it.  y may be nullptr when y2 is set.
+  const float* res;
+  int res_relu;
+  int8_t* y2;
+  float inv_scale2;
   // implicit GEMM (dense kh x kw, stride 1, dilation 1) on a zero-PADDED copy of the input [b][c][PH][PW]: im_kw > 0.
   // Then an "image" of the column space is one output row (NB = batch * OH, HWX = OW) and K-row k = (c, r, s) of it
   // starts at  x + ((b*C + c)*PH + oh + r)*PW + s : contiguous bytes, so the B tile still moves as 16-byte pieces.
@@ -123,6 +132,7 @@ struct PoolArgs {
   int is_max, exclusive;
 };
 void launch_pool2d(const PoolArgs& a, hipStream_t s);
+void launch_pool2d_max_i8(const PoolArgs& a, hipStream_t s);  // x / y are int8 planes behind the float pointers
 void launch_eltwise_add(const float* x, const float* y, float* o, int64_t count, int relu, hipStream_t s);
 
 }  // namespace plhip

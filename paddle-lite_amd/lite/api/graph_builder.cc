@@ -114,10 +114,84 @@ std::vector<GraphBuilder::Step> GraphBuilder::Schedule() {
   return steps;
 }
 
+void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
+  std::vector<Step>& st = *steps_io;
+  std::vector<bool> dead(st.size(), false);
+  auto uses = [&](const std::string& v) {
+    int n = 0;
+    for (size_t i = 0; i < st.size(); ++i) {
+      if (dead[i]) continue;
+      if (st[i].kind == "op") {
+        for (auto& in : st[i].op_inputs) n += in == v;
+        n += st[i].res == v;
+      } else {
+        n += st[i].in == v;
+      }
+    }
+    return n;
+  };
+  auto producer = [&](const std::string& v) {
+    for (size_t i = 0; i < st.size(); ++i)
+      if (!dead[i] && (st[i].out == v || (!st[i].calib_out.empty() && st[i].calib_out == v))) return static_cast<int>(i);
+    return -1;
+  };
+  auto is_f32_conv = [&](int i) {
+    return i >= 0 && st[i].kind == "op" && ops_[st[i].op].type == "conv2d" && ops_[st[i].op].enable_int8 && !st[i].int8_out &&
+           st[i].calib_out.empty() && !st[i].drop_f32;
+  };
+  // (A) elementwise_add (+relu) into the LATER of its fp32 conv producers, when that conv's output feeds only the add
+  for (size_t i = 0; i < st.size(); ++i) {
+    if (dead[i] || st[i].kind != "op") continue;
+    const GraphOp& op = ops_[st[i].op];
+    const bool plain = op.type == "elementwise_add", relu = op.type == "fusion_elementwise_add_activation" && op.act_type == "relu";
+    if (!plain && !relu) continue;
+    const int pa = producer(st[i].op_inputs[0]), pb = producer(st[i].op_inputs[1]);
+    int conv = -1, other = -1;
+    if (is_f32_conv(pb) && pb > pa && st[pb].res.empty() && uses(st[pb].out) == 1) conv = pb, other = 0;
+    else if (is_f32_conv(pa) && pa > pb && st[pa].res.empty() && uses(st[pa].out) == 1) conv = pa, other = 1;
+    if (conv < 0) continue;
+    st[conv].res = st[i].op_inputs[other];
+    st[conv].res_relu = relu;
+    st[conv].out = st[i].out;  // the conv now writes the sum
+    dead[i] = true;
+  }
+  // (C) conv[fp32_out] -> pool2d(max) -> calib: quantise in the conv, pool in int8
+  for (size_t i = 0; i < st.size(); ++i) {
+    if (dead[i] || st[i].kind != "calib_f2i") continue;
+    const int pp = producer(st[i].in);
+    if (pp < 0 || st[pp].kind != "op" || ops_[st[pp].op].type != "pool2d" || ops_[st[pp].op].pooling_type != "max") continue;
+    const int pc = producer(st[pp].op_inputs[0]);
+    if (!is_f32_conv(pc) || uses(st[pc].out) != 1 || uses(st[pp].out) != 1) continue;
+    st[pc].calib_out = st[pc].out + "/precision_trans";
+    st[pc].calib_scale = st[i].scale;
+    st[pc].drop_f32 = true;
+    st[pp].op_inputs[0] = st[pc].calib_out;
+    st[pp].out = st[i].out;
+    st[pp].pool_int8 = true;
+    dead[i] = true;
+  }
+  // (B) calib[fp32_to_int8] into the fp32 conv (possibly already carrying an add) that produces its input
+  for (size_t i = 0; i < st.size(); ++i) {
+    if (dead[i] || st[i].kind != "calib_f2i") continue;
+    const int pc = producer(st[i].in);
+    if (!is_f32_conv(pc) || st[pc].out != st[i].in) continue;
+    st[pc].calib_out = st[i].out;
+    st[pc].calib_scale = st[i].scale;
+    dead[i] = true;
+    st[pc].drop_f32 = uses(st[pc].out) == 0;
+  }
+  std::vector<Step> kept;
+  for (size_t i = 0; i < st.size(); ++i)
+    if (!dead[i]) kept.push_back(st[i]);
+  st.swap(kept);
+}
+
 std::vector<std::string> GraphBuilder::Plan() {
   std::vector<std::string> lines;
   char buf[64];
-  for (auto& s : Schedule()) {
+  auto steps = Schedule();
+  if (fuse_) FuseSteps(&steps);
+  for (auto& s : steps) {
     std::string l;
     if (s.kind == "op") {
       const GraphOp& op = ops_[s.op];
@@ -135,6 +209,13 @@ std::vector<std::string> GraphBuilder::Plan() {
         snprintf(buf, sizeof buf, " oscale=%.9g", s.out_scale);
         l += buf;
       }
+      if (!s.res.empty()) l += std::string(" +add=") + s.res + (s.res_relu ? " +relu" : "");
+      if (!s.calib_out.empty()) {
+        snprintf(buf, sizeof buf, " scale=%.9g", s.calib_scale);
+        l += " +calib=" + s.calib_out + buf;
+      }
+      if (s.drop_f32) l += " -f32";
+      if (s.pool_int8) l += " int8";
     } else {
       l = s.kind == "io_copy_h2d" ? "io_copy/host_to_device"
           : s.kind == "io_copy_d2h" ? "io_copy/device_to_host"
@@ -153,7 +234,9 @@ std::vector<std::string> GraphBuilder::Plan() {
 std::vector<std::string> GraphBuilder::Lower(HipPredictor* pred) {
   for (auto& f : feeds_) pred->AddFeed(f.name, f.dims, f.prec);
   std::vector<std::string> outs;
-  for (auto& s : Schedule()) {
+  auto steps = Schedule();
+  if (fuse_) FuseSteps(&steps);
+  for (auto& s : steps) {
     if (s.kind == "io_copy_h2d") {
       pred->AddIoCopy(s.in, s.out, true);
     } else if (s.kind == "io_copy_d2h") {
@@ -168,6 +251,11 @@ std::vector<std::string> GraphBuilder::Lower(HipPredictor* pred) {
         ConvAttrs a = op.conv;
         a.int8_out = s.int8_out;
         a.output_scale = s.int8_out ? s.out_scale : 1.f;
+        a.residual = s.res;
+        a.residual_relu = s.res_relu;
+        a.calib_out = s.calib_out;
+        a.calib_scale = s.calib_scale;
+        a.drop_fp32 = s.drop_f32;
         pred->AddConv(op.type, s.op_inputs[0], s.out, op.w.data(), op.w_dims, op.has_bias ? op.bias.data() : nullptr, a);
       } else if (op.type == "fc") {
         CHECK(op.enable_int8) << "kHIP has int8 fc kernels only";
@@ -176,7 +264,7 @@ std::vector<std::string> GraphBuilder::Lower(HipPredictor* pred) {
                     s.int8_out ? s.out_scale : 1.f, s.int8_out, op.fc_relu);
       } else if (op.type == "pool2d") {
         pred->AddPool(s.op_inputs[0], s.out, op.pooling_type, op.ksize, op.pool_strides, op.pool_paddings,
-                      op.global_pooling, op.exclusive, op.ceil_mode);
+                      op.global_pooling, op.exclusive, op.ceil_mode, s.pool_int8);
       } else if (op.type == "elementwise_add") {
         pred->AddElementwiseAdd(s.op_inputs[0], s.op_inputs[1], s.out, "");
       } else if (op.type == "fusion_elementwise_add_activation") {

@@ -48,6 +48,11 @@ class GraphBuilder {
  public:
   void Feed(const std::string& name, const std::vector<int64_t>& dims, PrecisionType prec);
   void Fetch(const std::string& name) { fetches_.push_back(name); }
+  // Graph-level fusions of the kHIP target on top of the reference's program (default on; results are bit-identical to
+  // the unfused program, every fused value is rounded as the separate instructions round it):
+  //   conv2d[fp32_out] -> elementwise_add | fusion_elementwise_add_activation(relu) -> calib   => ONE conv launch
+  //   conv2d[fp32_out] -> pool2d(max) -> calib                                  => conv + fused calib, int8 max pool
+  void set_fuse(bool on) { fuse_ = on; }
   GraphOp& Add(const std::string& type, const std::vector<std::string>& inputs, const std::string& output);
   // Emits the program into `pred`; returns the host-side names of the fetched variables ("<name>/host").
   std::vector<std::string> Lower(HipPredictor* pred);
@@ -64,13 +69,22 @@ class GraphBuilder {
     bool int8_out{false};
     float out_scale{1.f};
     std::vector<std::string> op_inputs;  // op inputs after cast renaming
+    // kHIP fusions (FuseSteps): tail taken over by an fp32_out conv, int8 max pool behind a fused calib
+    std::string res;          // residual operand of the fused elementwise_add ("" = none)
+    bool res_relu{false};
+    std::string calib_out;    // int8 tensor of the fused calib ("" = none)
+    float calib_scale{1.f};
+    bool drop_f32{false};     // the fp32 output has no consumer left
+    bool pool_int8{false};    // pool2d(max) moved behind the calib: max commutes with the monotonic quantiser
   };
   std::vector<Step> Schedule();
+  void FuseSteps(std::vector<Step>* steps);
   struct FeedDesc {
     std::string name;
     std::vector<int64_t> dims;
     PrecisionType prec;
   };
+  bool fuse_{true};
   std::vector<FeedDesc> feeds_;
   std::vector<std::string> fetches_;
   std::vector<GraphOp> ops_;

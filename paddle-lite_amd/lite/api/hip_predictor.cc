@@ -96,6 +96,19 @@ void HipPredictor::AddConv(const std::string& op_type, const std::string& in, co
     if (a.act == 2) p.activation_param.Relu_clipped_coef = a.act_coef;
     if (a.act == 4) p.activation_param.Leaky_relu_alpha = a.act_coef;
   }
+  if (!a.residual.empty()) {
+    CHECK(!a.int8_out) << "the fused residual add belongs to the fp32_out kernel";
+    p.fuse_residual_connection = true;
+    p.residualData = Var(a.residual);
+    p.fuse_residual_relu = a.residual_relu;
+  }
+  if (!a.calib_out.empty()) {
+    CHECK(!a.int8_out) << "the fused calib belongs to the fp32_out kernel";
+    p.calib_output = Var(a.calib_out);
+    p.calib_output->set_precision(PRECISION(kInt8));
+    p.calib_scale = a.calib_scale;
+    p.drop_fp32_output = a.drop_fp32;
+  }
   op->set_padding_algorithm(a.padding_algorithm);
   Emit(op, PickKernel(op_type, Place(TARGET(kHIP), PRECISION(kInt8)), a.int8_out ? "int8_out" : "fp32_out"));
 }
@@ -131,7 +144,7 @@ void HipPredictor::AddGlobalAvgPool(const std::string& in, const std::string& ou
 
 void HipPredictor::AddPool(const std::string& in, const std::string& out, const std::string& pooling_type,
                            const std::vector<int>& ksize, const std::vector<int>& strides, const std::vector<int>& paddings,
-                           bool global_pooling, bool exclusive, bool ceil_mode) {
+                           bool global_pooling, bool exclusive, bool ceil_mode, bool int8) {
   auto op = std::make_shared<operators::PoolOpLite>();
   auto& p = op->mutable_param();
   p.x = Var(in);
@@ -143,7 +156,7 @@ void HipPredictor::AddPool(const std::string& in, const std::string& out, const 
   p.exclusive = exclusive;
   p.ceil_mode = ceil_mode;
   p.paddings = std::make_shared<std::vector<int>>(paddings);
-  Emit(op, PickKernel("pool2d", Place(TARGET(kHIP), PRECISION(kFloat)), "def"));
+  Emit(op, PickKernel("pool2d", Place(TARGET(kHIP), int8 ? PRECISION(kInt8) : PRECISION(kFloat)), "def"));
 }
 
 void HipPredictor::AddElementwiseAdd(const std::string& x, const std::string& y, const std::string& out,

@@ -31,6 +31,10 @@ struct ConvAttrs {
   std::vector<float> weight_scale;
   bool int8_out{true};
   std::string padding_algorithm{""};
+  // kHIP fused tail of an fp32_out conv (op_params.h ConvParam, graph_builder.h): variable names, "" = none
+  std::string residual, calib_out;
+  bool residual_relu{false}, drop_fp32{false};
+  float calib_scale{1.f};
 };
 
 class HipPredictor {
@@ -50,7 +54,7 @@ class HipPredictor {
   void AddGlobalAvgPool(const std::string& in, const std::string& out);
   void AddPool(const std::string& in, const std::string& out, const std::string& pooling_type, const std::vector<int>& ksize,
                const std::vector<int>& strides, const std::vector<int>& paddings, bool global_pooling, bool exclusive,
-               bool ceil_mode);
+               bool ceil_mode, bool int8 = false);
   // act_type "" -> elementwise_add, "relu" -> fusion_elementwise_add_activation
   void AddElementwiseAdd(const std::string& x, const std::string& y, const std::string& out, const std::string& act_type);
   void AddSoftmax(const std::string& in, const std::string& out);

@@ -188,6 +188,9 @@ int pllite_graph_elementwise_add(pllite_predictor* p, const char* x, const char*
 int pllite_graph_softmax(pllite_predictor* p, const char* in, const char* out) {
   return guarded([&] { p->graph.Add("softmax", {in}, out); });
 }
+int pllite_graph_set_fuse(pllite_predictor* p, int on) {
+  return guarded([&] { p->graph.set_fuse(on != 0); });
+}
 int pllite_graph_fetch(pllite_predictor* p, const char* name) {
   return guarded([&] { p->graph.Fetch(name); });
 }

@@ -53,6 +53,8 @@ int pllite_graph_pool(pllite_predictor* p, const char* in, const char* out, cons
 int pllite_graph_elementwise_add(pllite_predictor* p, const char* x, const char* y, const char* out, const char* act_type);
 int pllite_graph_softmax(pllite_predictor* p, const char* in, const char* out);
 int pllite_graph_fetch(pllite_predictor* p, const char* name);
+/* kHIP graph-level fusions (graph_builder.h set_fuse): on by default; 0 = the reference program instruction for instruction. */
+int pllite_graph_set_fuse(pllite_predictor* p, int on);
 /* '\n'-separated plan (GraphBuilder::Plan) — needs no device. */
 int pllite_graph_plan(pllite_predictor* p, char* buf, int cap);
 /* Emit the program into the predictor; '\n'-separated host names of the fetched variables in buf. */

@@ -154,10 +154,29 @@ void ConvCompute<Ptype, OutType>::Run() {
     y = param.output->template mutable_data<int8_t>(TARGET(kHIP));
     kind = PLHIP_OUT_I8;
   } else {
-    y = param.output->template mutable_data<float>(TARGET(kHIP));
+    // a fused tail may leave the fp32 tensor without consumers (drop_fp32_output): then it is never allocated
+    y = param.drop_fp32_output ? nullptr : param.output->template mutable_data<float>(TARGET(kHIP));
     kind = PLHIP_OUT_F32;
   }
-  if (is_depthwise_) {
+  const bool fused_tail = OutType == PRECISION(kFloat) && (param.fuse_residual_connection || param.calib_output != nullptr);
+  if (fused_tail) {
+    CHECK(!is_depthwise_) << "kHIP: the fused conv tail exists on the GEMM-like convs only";
+    const float* res = nullptr;
+    if (param.fuse_residual_connection) {
+      CHECK(param.residualData && param.residualData->target() == TARGET(kHIP)) << "fused residual operand must live on the device";
+      CHECK(param.residualData->dims() == param.output->dims()) << "fused residual operand must have the output's shape";
+      res = param.residualData->template data<float>();
+    }
+    int8_t* q = nullptr;
+    if (param.calib_output) {
+      param.calib_output->Resize(param.output->dims());
+      q = param.calib_output->template mutable_data<int8_t>(TARGET(kHIP));
+    }
+    void* ws = workspace_bytes_ ? ctx.workspace(workspace_bytes_) : nullptr;
+    HIP_CALL(ctx.ctx(), plhip_conv2d_int8_fused(ctx.ctx(), &desc_, x, weights_.raw_data(), sc, bi,
+                                                param.drop_fp32_output ? nullptr : static_cast<float*>(y), res,
+                                                param.fuse_residual_relu ? 1 : 0, q, param.calib_scale, ws, workspace_bytes_));
+  } else if (is_depthwise_) {
     HIP_CALL(ctx.ctx(), plhip_depthwise_conv_int8(ctx.ctx(), &desc_, x, weights_.data<int8_t>(), sc, bi, y, kind));
   } else {
     void* ws = workspace_bytes_ ? ctx.workspace(workspace_bytes_) : nullptr;

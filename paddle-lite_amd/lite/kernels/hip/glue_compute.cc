@@ -111,6 +111,36 @@ class PoolCompute : public KernelLite<TARGET(kHIP), PRECISION(kFloat)> {
   std::string kernel_func_name_{"pooling_hip"};
 };
 
+// int8 max pool: exists only as the product of graph_builder.cc's fusion (C): conv -> pool2d(max) -> calib becomes
+// conv + fused calib -> this kernel; bit-identical because max commutes with the monotonic quantiser.
+class PoolMaxInt8Compute : public KernelLite<TARGET(kHIP), PRECISION(kInt8)> {
+ public:
+  void Run() override {
+    auto& param = this->Param<operators::PoolParam>();
+    auto& ctx = this->ctx_->As<HIPContext>();
+    CHECK(param.pooling_type == "max" && !param.global_pooling && !param.adaptive) << "kHIP int8 pool2d: max windows only";
+    const auto d = param.x->dims();
+    const auto o = param.output->dims();
+    const auto& pads = *param.paddings;
+    plhip_pool_desc pd;
+    pd.planes = static_cast<int>(d[0] * d[1]);
+    pd.h = static_cast<int>(d[2]);
+    pd.w = static_cast<int>(d[3]);
+    pd.oh = static_cast<int>(o[2]);
+    pd.ow = static_cast<int>(o[3]);
+    pd.kh = param.ksize[0];
+    pd.kw = param.ksize[1];
+    for (int i = 0; i < 4; ++i) pd.pad[i] = pads[i];
+    pd.stride[0] = param.strides[0];
+    pd.stride[1] = param.strides[1];
+    pd.is_max = 1;
+    pd.exclusive = 1;
+    HIP_CALL(ctx.ctx(), plhip_pool2d_max_i8(ctx.ctx(), &pd, param.x->data<int8_t>(),
+                                            param.output->mutable_data<int8_t>(TARGET(kHIP))));
+  }
+  void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = "pooling_max_int8_hip"; }
+};
+
 // elementwise_add, fp32, same-shape operands (elementwise_compute.cc:182-190)
 class ElementwiseAddCompute : public KernelLite<TARGET(kHIP), PRECISION(kFloat)> {
  public:
@@ -179,6 +209,10 @@ REGISTER_LITE_KERNEL(io_copy, kHIP, kAny, kAny, paddle::lite::kernels::hip::IoCo
 REGISTER_LITE_KERNEL(pool2d, kHIP, kFloat, kNCHW, paddle::lite::kernels::hip::PoolCompute, def)
     .BindInput("X", {LiteType::GetTensorTy(TARGET(kHIP))})
     .BindOutput("Out", {LiteType::GetTensorTy(TARGET(kHIP))})
+    .Finalize();
+REGISTER_LITE_KERNEL(pool2d, kHIP, kInt8, kNCHW, paddle::lite::kernels::hip::PoolMaxInt8Compute, def)
+    .BindInput("X", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
+    .BindOutput("Out", {LiteType::GetTensorTy(TARGET(kHIP), PRECISION(kInt8))})
     .Finalize();
 REGISTER_LITE_KERNEL(elementwise_add, kHIP, kFloat, kNCHW, paddle::lite::kernels::hip::ElementwiseAddCompute, def)
     .BindInput("X", {LiteType::GetTensorTy(TARGET(kHIP))})

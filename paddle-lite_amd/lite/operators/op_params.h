@@ -87,6 +87,15 @@ struct ConvParam : ParamBase {
   bool var_length{false};
   std::vector<int> output_size;
   WITH_INT8_CONFIG
+  // ---- kHIP graph-level fusion (not in the reference's struct; set only by lite/api/graph_builder.cc): the fp32_out
+  // kernel can take over the instructions that follow it in the reference program.  residualData (above, the
+  // reference's own field, lite/operators/conv_op.h:102) is the other operand of the fused elementwise_add;
+  // fuse_residual_relu = the add was a fusion_elementwise_add_activation(relu); calib_output = the int8 tensor a following
+  // calib[fp32_to_int8] with scale calib_scale would produce; drop_fp32_output = `output` has no other consumer.
+  bool fuse_residual_relu{false};
+  lite::Tensor* calib_output{nullptr};
+  float calib_scale{1.f};
+  bool drop_fp32_output{false};
 };
 
 struct PoolParam : ParamBase {

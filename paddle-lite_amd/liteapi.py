@@ -52,6 +52,7 @@ def load():
     L.pllite_graph_elementwise_add.argtypes = [vp, cs, cs, cs, cs]
     L.pllite_graph_softmax.argtypes = [vp, cs, cs]
     L.pllite_graph_fetch.argtypes = [vp, cs]
+    L.pllite_graph_set_fuse.argtypes = [vp, i32]
     L.pllite_graph_plan.argtypes = [vp, cs, i32]
     L.pllite_graph_lower.argtypes = [vp, cs, i32]
     L.pllite_set_input.argtypes = [vp, cs, vp, i64]
@@ -183,6 +184,9 @@ class Predictor:
 
     def graph_softmax(self, src, dst):
         self._ck(self.L.pllite_graph_softmax(self.h, src.encode(), dst.encode()))
+
+    def graph_set_fuse(self, on):
+        self._ck(self.L.pllite_graph_set_fuse(self.h, int(on)))
 
     def graph_fetch(self, name):
         self._ck(self.L.pllite_graph_fetch(self.h, name.encode()))

@@ -270,9 +270,11 @@ def net_stats(net):
     return macs
 
 
-def emit_graph(pred, net, batch):
-    """Feed the op list to the predictor's graph mode and lower it.  Returns the host name of the output variable."""
+def emit_graph(pred, net, batch, fuse=True):
+    """Feed the op list to the predictor's graph mode and lower it.  Returns the host name of the output variable.
+    fuse=False: the reference program instruction for instruction (no kHIP graph-level fusion)."""
     from . import liteapi
+    pred.graph_set_fuse(fuse)
     c, h, w = net["input_shape"]
     pred.graph_feed(net["input"], (batch, c, h, w), liteapi.PREC_FLOAT)
     for o in net["ops"]:

@@ -102,10 +102,10 @@ def test_fc_kernel_classes_pick_the_reference_route(lite, plref):
         assert np.array_equal(y, ref), (ws.size, int8_out)
 
 
-def _run_graph(lite, wl, net, img):
+def _run_graph(lite, wl, net, img, fuse=False):
     p = lite.Predictor(0)
     try:
-        out = wl.emit_graph(p, net, img.shape[0])
+        out = wl.emit_graph(p, net, img.shape[0], fuse=fuse)
         fetched = p.graph_lower()
         assert fetched == [out]
         p.set_input(net["input"], img)
@@ -240,3 +240,82 @@ def test_implicit_gemm_short_rows_and_small_m(gpu_ctx, plref, pkg):
                 assert np.array_equal(y, ref), (cin, cout, hw)
             else:
                 np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("which", ["resnet50", "mobilenet_v2"])
+def test_fused_programs_equal_the_oracle_graph(lite, wl, plref, which):
+    """Default (fused) lowering: conv + residual add + relu + calib in one launch, int8 max pool behind the stem.  Every
+    variable the fused program still produces must equal the oracle's variable of the same name: int8 bit for bit, fp32
+    within 1e-5 — i.e. the fusion changes the instruction count, not one byte of the data."""
+    net = wl.resnet50_net() if which == "resnet50" else wl.mobilenet_v2_net()
+    img = np.random.default_rng(340).uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+    ref = graph_oracle.forward(plref, net, img)
+    p, out = _run_graph(lite, wl, net, img, fuse=True)
+    try:
+        plan = p.graph_plan()
+        assert len(plan) == (61 if which == "resnet50" else 59)
+        live = set()
+        for l in plan:
+            o = l.split(" out=")[1].split(" ")[0]
+            if not l.endswith("-f32") and " -f32" not in l:
+                live.add(o)
+            if "+calib=" in l:
+                live.add(l.split("+calib=")[1].split(" ")[0])
+        n_i8 = 0
+        for name, want in ref.items():
+            if name not in live:
+                continue
+            got = p.get_var(name, want.dtype)
+            assert got.shape == want.shape, name
+            if want.dtype == np.int8:
+                assert np.array_equal(got, want), "%s: %d of %d int8 values differ" % (name, (got != want).sum(), want.size)
+                n_i8 += 1
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=name)
+        assert n_i8 >= (49 if which == "resnet50" else 50)
+        np.testing.assert_allclose(p.get_var(out, np.float32), ref["prob"], rtol=1e-4, atol=1e-7)
+    finally:
+        p.close()
+
+
+def test_fused_conv_tail_through_the_c_abi(gpu_ctx, plref, pkg):
+    """plhip_conv2d_int8_fused == conv[fp32_out] ; elementwise_add (+relu) ; calib, run one by one through the oracle:
+    1x1 (first- and second-generation GEMM kernels), implicit 3x3, ragged HW, with and without each stage."""
+    capi = pkg.capi
+    rng = np.random.default_rng(341)
+    for (n, cin, cout, hw, k, pad) in [(2, 64, 256, 14, 1, 0), (3, 16, 24, 7, 1, 0), (2, 160, 96, 9, 1, 0), (2, 32, 64, 14, 3, 1),
+                                       (1, 512, 128, 28, 1, 0)]:
+        x = rng.integers(-127, 128, (n, cin, hw, hw)).astype(np.int8)
+        w = rng.integers(-127, 128, (cout, cin, k, k)).astype(np.int8)
+        bias = rng.uniform(-1, 1, cout).astype(np.float32)
+        wsc = ((1 + np.arange(cout) % 7) / 127.0 / 4.0).astype(np.float32)
+        d = capi.conv_desc(n, cin, hw, hw, cout, k, k, (pad,) * 4, (1, 1), (1, 1), 1, capi.ACT_NONE, 0.0)
+        s = plref.shape(n, cin, hw, hw, cout, k, k, (pad,) * 4, (1, 1), (1, 1), 1)
+        sc, bi, _ = plref.fold_scales(0, 1 / 127.0, wsc, 1.0, bias, cout, 0, 0.0)
+        y_ref, _ = plref.conv2d(s, x, w, bias, 1 / 127.0, wsc, 1.0, 0, 0.0, False)
+        res = rng.standard_normal(y_ref.shape).astype(np.float32) * np.float32(y_ref.std())
+        cs = float(np.abs(y_ref).max() / 100.0)
+        for (use_res, relu, use_calib, want_f32) in [(True, True, True, True), (True, False, True, False), (False, False, True, True),
+                                                     (True, True, False, True), (False, False, True, False)]:
+            z = plref.elementwise_add(y_ref, res, relu) if use_res else y_ref
+            q = plref.calib_f32_to_i8(z, cs) if use_calib else None
+            yf, yq = gpu_ctx.conv2d_fused(d, x, w, sc, bi, res if use_res else None, relu, cs if use_calib else None, want_f32)
+            if want_f32:
+                np.testing.assert_allclose(yf, z, rtol=1e-5, atol=1e-6)
+            if use_calib:
+                # the int8 copy must be the quantisation of the fp32 values THIS launch produced (bit for bit when those
+                # equal the oracle's, which they do except for fma-contraction-free ties: checked through yf when present)
+                assert np.array_equal(yq, q), (cin, cout, hw, k, use_res, relu, int((yq != q).sum()))
+
+
+def test_int8_max_pool_commutes_with_calib(gpu_ctx, plref):
+    rng = np.random.default_rng(342)
+    x = (rng.standard_normal((2, 64, 112, 112)) * 1.5).astype(np.float32)
+    scale = 4.0 / 127
+    a = plref.calib_f32_to_i8(plref.pool2d(x, "max", (3, 3), (2, 2), (1, 1, 1, 1)), scale)
+    b = gpu_ctx.pool2d(plref.calib_f32_to_i8(x, scale), "max", (3, 3), (2, 2), (1, 1, 1, 1))
+    assert b.dtype == np.int8 and np.array_equal(a, b)
+    for (h, w, k, s, pads) in [(7, 9, 2, 2, (0, 0, 0, 0)), (13, 17, 3, 2, (0, 1, 1, 2)), (6, 6, 3, 3, (1, 1, 1, 1))]:
+        xi = rng.integers(-127, 128, (2, 3, h, w)).astype(np.int8)
+        want = plref.pool2d(xi.astype(np.float32), "max", (k, k), (s, s), pads).astype(np.int8)
+        assert np.array_equal(gpu_ctx.pool2d(xi, "max", (k, k), (s, s), pads), want)

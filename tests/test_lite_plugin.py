@@ -30,6 +30,7 @@ def test_registry_has_reference_kernel_set(lite):
     assert L.pllite_registered_kernels(b"calib", lite.PREC_INT8, lite.LAYOUT_NCHW) == 2
     assert L.pllite_registered_kernels(b"io_copy", lite.PREC_ANY, lite.LAYOUT_ANY) == 2
     assert L.pllite_registered_kernels(b"pool2d", lite.PREC_FLOAT, lite.LAYOUT_NCHW) == 1
+    assert L.pllite_registered_kernels(b"pool2d", lite.PREC_INT8, lite.LAYOUT_NCHW) == 1  # product of the kHIP graph fusion
     # fp32-only on the reference's ARM target too (elementwise_compute.cc:385-412)
     assert L.pllite_registered_kernels(b"elementwise_add", lite.PREC_FLOAT, lite.LAYOUT_NCHW) == 1
     assert L.pllite_registered_kernels(b"fusion_elementwise_add_activation", lite.PREC_FLOAT, lite.LAYOUT_NCHW) == 1
