@@ -312,12 +312,14 @@ def program_costs(net, batch, plan_lines):
         c, h, w = shapes[base]
         return batch * c * h * w
 
-    by_name = {o["name"]: o for o in net["ops"]}
+    int8_ops = iter([o for o in net["ops"] if o["op"] in ("conv2d", "depthwise_conv2d", "fc")])  # never reordered
     out = []
     esz[net["input"]] = 4
     for line in plan_lines:
         head, rest = line.split(" ", 1)
-        kv = dict(f.split("=", 1) for f in rest.split(" "))
+        toks = rest.split(" ")
+        kv = dict(f.split("=", 1) for f in toks if "=" in f)
+        flags = {f for f in toks if "=" not in f}
         ins, dst = kv["in"].split(","), kv["out"]
         op, alias = head.split("/")
         if op == "io_copy":
@@ -328,8 +330,9 @@ def program_costs(net, batch, plan_lines):
             esz[dst] = 1 if alias == "fp32_to_int8" else 4
             out.append(dict(name=dst, family="calib", ops=0, bytes=numel(ins[0]) * esz[ins[0]] + numel(dst) * esz[dst]))
             continue
-        o = by_name[dst]
         if op in ("conv2d", "depthwise_conv2d", "fc"):
+            o = next(int8_ops)
+            assert o["op"] == op, (o["op"], line)
             esz[dst] = 1 if alias in ("int8_out", "int8out") else 4
             wbytes = int(o["w"].size)
             if op == "fc":
@@ -337,7 +340,7 @@ def program_costs(net, batch, plan_lines):
                 fam = "fc"
             else:
                 cout, cg, k, _ = o["w"].shape
-                c, h, w = shapes[dst]
+                c, h, w = shapes[o["name"]]
                 macs = batch * h * w * cout * cg * k * k
                 cin = shapes[o["src"]][0]
                 if op == "depthwise_conv2d":
@@ -346,10 +349,17 @@ def program_costs(net, batch, plan_lines):
                     fam = "pointwise1x1" if o["stride"] == 1 else "conv1x1s2"
                 else:
                     fam = "stem_conv" if cin <= 4 else "conv%dx%d" % (k, k)
-            byts = sum(numel(i) * esz[i] for i in ins) + numel(dst) * esz[dst] + wbytes
+            byts = sum(numel(i) * esz[i] for i in ins) + wbytes
+            if "-f32" not in flags:
+                byts += numel(dst) * esz[dst]
+            if "+add" in kv:      # fused residual operand (fp32)
+                byts += numel(kv["+add"]) * 4
+            if "+calib" in kv:    # fused int8 copy
+                esz[kv["+calib"]] = 1
+                byts += numel(kv["+calib"])
             out.append(dict(name=dst, family=fam, ops=2 * macs, bytes=byts))
         else:
-            esz[dst] = 4
+            esz[dst] = 1 if "int8" in flags else 4
             fam = {"pool2d": "pool2d", "elementwise_add": "elementwise_add", "fusion_elementwise_add_activation": "elementwise_add",
                    "softmax": "softmax"}[op]
             out.append(dict(name=dst, family=fam, ops=0, bytes=sum(numel(i) * esz[i] for i in ins) + numel(dst) * esz[dst]))
