@@ -977,9 +977,12 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
     dbg_env = e ? atoi(e) : 0;
   }
   g.dbg = dbg_env;
-  // MFMA-heavy shapes: the transposed-read ring kernel (gemm_tr_i8.hip).  It moves END-aligned 16-byte pieces and must
-  // know the TRUE row length of a dense slab (HW = 49: the dword kernels get it rounded up to 4).
-  if (g.M > 32 && (gemm_variant() == 0 || g.im_kw > 0) && (dbg_env & ~96) == 0) {
+  // The transposed-read ring kernel (gemm_tr_i8.hip) is the implicit-GEMM engine (any M > 32, rows down to 7 columns).
+  // For plain 1x1 / im2col GEMMs it is opt-in (PLHIP_GEMM_TR=2): measured on MobileNetV1's pointwise layers it ties
+  // the first-generation ring kernel at batch 128 and loses at batch 256 (both are bound by the
+  // ~21 B/clk a CU ingests through LDS-DMA and by the non-overlapped epilogue, not by the K loop's instruction mix).
+  // It moves END-aligned 16-byte pieces and must know the TRUE row length of a dense slab (HW = 49).
+  if (g.M > 32 && (g.im_kw > 0 || (gemm_variant() == 0 && gemm_tr_enabled() >= 2)) && (dbg_env & ~96) == 0) {
     GemmArgs t = g;
     if (t.im_kw == 0 && t.XP > 0 && t.XP < t.HWX) t.HWX = t.XP;
     if (launch_gemm_tr(t, out, s)) return;
