@@ -59,6 +59,7 @@ class GraphBuilder {
   // The decisions of passes 1-3 as text, one instruction per line (CPU-testable without a device):
   //   "conv2d/int8_out in=a out=b oscale=0.031496"   "calib/fp32_to_int8 in=x out=x/precision_trans scale=..."
   std::vector<std::string> Plan();
+  const std::vector<GraphOp>& ops() const { return ops_; }
 
  private:
   struct Step {

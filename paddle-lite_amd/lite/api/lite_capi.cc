@@ -7,6 +7,7 @@
 #include "lite/api/graph_builder.h"
 #include "lite/api/hip_predictor.h"
 #include "lite/core/profile/timer.h"
+#include "lite/model_parser/hip_model.h"
 
 using paddle::lite::HipPredictor;
 using paddle::lite::Tensor;
@@ -205,6 +206,38 @@ int pllite_graph_plan(pllite_predictor* p, char* buf, int cap) {
 }
 int pllite_graph_lower(pllite_predictor* p, char* buf, int cap) {
   return guarded([&] { join_lines(p->graph.Lower(&p->pred), buf, cap); });
+}
+
+int pllite_load_model(pllite_predictor* p, const void* bytes, int64_t nbytes, int batch) {
+  return guarded([&] {
+    CHECK(bytes && nbytes > 16 && batch > 0) << "pllite_load_model: bad argument";
+    const uint8_t* b = static_cast<const uint8_t*>(bytes);
+    std::vector<uint8_t> v(b, b + nbytes);
+    auto model = paddle::lite::model_parser::ParseContainer(v);
+    paddle::lite::model_parser::BuildGraph(&model, batch, &p->graph);
+  });
+}
+int pllite_graph_num_ops(pllite_predictor* p) { return static_cast<int>(p->graph.ops().size()); }
+int pllite_graph_op_params(pllite_predictor* p, int index, char* type, int type_cap, int8_t* w, int64_t* n_w, float* bias,
+                           int* n_bias, float* weight_scale, int* n_scale, float* input_scale, int* act, float* act_coef) {
+  return guarded([&] {
+    const auto& ops = p->graph.ops();
+    CHECK(index >= 0 && index < static_cast<int>(ops.size())) << "op index out of range";
+    const auto& o = ops[index];
+    if (type && type_cap > 0) {
+      std::strncpy(type, o.type.c_str(), static_cast<size_t>(type_cap) - 1);
+      type[type_cap - 1] = 0;
+    }
+    if (n_w) *n_w = static_cast<int64_t>(o.w.size());
+    if (n_bias) *n_bias = o.has_bias ? static_cast<int>(o.bias.size()) : 0;
+    if (n_scale) *n_scale = static_cast<int>(o.conv.weight_scale.size());
+    if (w) std::memcpy(w, o.w.data(), o.w.size());
+    if (bias && o.has_bias) std::memcpy(bias, o.bias.data(), o.bias.size() * sizeof(float));
+    if (weight_scale) std::memcpy(weight_scale, o.conv.weight_scale.data(), o.conv.weight_scale.size() * sizeof(float));
+    if (input_scale) *input_scale = o.conv.input_scale;
+    if (act) *act = o.conv.act;
+    if (act_coef) *act_coef = o.conv.act_coef;
+  });
 }
 
 int pllite_set_input(pllite_predictor* p, const char* name, const void* host, int64_t bytes) {

@@ -62,6 +62,16 @@ int pllite_graph_lower(pllite_predictor* p, char* buf, int cap);
 /* A predictor object that can only plan (no device needed): for CPU tests of the lowering rules. */
 pllite_predictor* pllite_predictor_create_planner(void);
 
+/* ---- model ingestion (lite/model_parser/hip_model.h): parses a PLHIPM01 container, applies the reference's
+ * quant/dequant, conv+bn, conv+activation, fc and elementwise+activation fusion semantics and fills the predictor's
+ * graph (then: pllite_graph_plan / pllite_graph_lower).  Needs no device. ---- */
+int pllite_load_model(pllite_predictor* p, const void* bytes, int64_t nbytes, int batch);
+/* The fused parameters of graph op `index` (conv2d / depthwise_conv2d / fc) for inspection: element counts through
+ * n_w / n_bias / n_scale; arrays are copied when the pointers are non-null (capacity = the counts of a first call). */
+int pllite_graph_num_ops(pllite_predictor* p);
+int pllite_graph_op_params(pllite_predictor* p, int index, char* type, int type_cap, int8_t* w, int64_t* n_w, float* bias,
+                           int* n_bias, float* weight_scale, int* n_scale, float* input_scale, int* act, float* act_coef);
+
 int pllite_set_input(pllite_predictor* p, const char* name, const void* host, int64_t bytes);
 int pllite_run(pllite_predictor* p, int skip_io_copy);
 int pllite_sync(pllite_predictor* p);

@@ -55,6 +55,10 @@ def load():
     L.pllite_graph_set_fuse.argtypes = [vp, i32]
     L.pllite_graph_plan.argtypes = [vp, cs, i32]
     L.pllite_graph_lower.argtypes = [vp, cs, i32]
+    L.pllite_load_model.argtypes = [vp, vp, i64, i32]
+    L.pllite_graph_num_ops.argtypes = [vp]
+    L.pllite_graph_op_params.argtypes = [vp, i32, cs, i32, vp, C.POINTER(i64), vp, C.POINTER(i32), vp, C.POINTER(i32),
+                                         C.POINTER(f32), C.POINTER(i32), C.POINTER(f32)]
     L.pllite_set_input.argtypes = [vp, cs, vp, i64]
     L.pllite_run.argtypes = [vp, i32]
     L.pllite_sync.argtypes = [vp]
@@ -200,6 +204,28 @@ class Predictor:
         buf = C.create_string_buffer(1 << 14)
         self._ck(self.L.pllite_graph_lower(self.h, buf, len(buf)))
         return [s for s in buf.value.decode().split("\n") if s]
+
+    def load_model(self, blob, batch):
+        """Parse a PLHIPM01 container (bytes) into the predictor's graph (lite/model_parser/hip_model.h)."""
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._ck(self.L.pllite_load_model(self.h, buf, len(blob), batch))
+
+    def graph_ops(self):
+        """[(type, w int8 flat, bias or None, weight_scale, input_scale, act, act_coef)] of the graph's ops."""
+        res = []
+        for i in range(self.L.pllite_graph_num_ops(self.h)):
+            t = C.create_string_buffer(64)
+            nw, nb, ns = C.c_int64(), C.c_int(), C.c_int()
+            isc, act, coef = C.c_float(), C.c_int(), C.c_float()
+            self._ck(self.L.pllite_graph_op_params(self.h, i, t, 64, None, C.byref(nw), None, C.byref(nb), None, C.byref(ns),
+                                                   C.byref(isc), C.byref(act), C.byref(coef)))
+            w = np.empty(nw.value, np.int8)
+            b = np.empty(nb.value, np.float32)
+            s_ = np.empty(ns.value, np.float32)
+            self._ck(self.L.pllite_graph_op_params(self.h, i, None, 0, w.ctypes.data_as(C.c_void_p), None,
+                                                   b.ctypes.data_as(C.c_void_p), None, s_.ctypes.data_as(C.c_void_p), None, None, None, None))
+            res.append((t.value.decode(), w, b if nb.value else None, s_, isc.value, act.value, coef.value))
+        return res
 
     def set_input(self, name, arr):
         arr = np.ascontiguousarray(arr)

@@ -1,0 +1,129 @@
+"""Quantised-model ingestion: the PLHIPM01 container written by paddle-lite_amd/modelfile.py, read by
+the C++ loader (lite/model_parser/hip_model.cc), which applies the reference's quant_dequant_op_fuser / conv_bn_fuser /
+activation / fc / elementwise fusion semantics.  CPU: the loader's fused int8 weights, per-channel scales, biases, input
+scales and activations equal a numpy restatement of those passes value for value, and the lowered plan equals the plan of
+the same network built in code.  GPU: the loaded program's variables equal the in-code program's and the oracle's."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import graph_oracle
+
+
+@pytest.fixture(scope="module")
+def lite(pkg):
+    return importlib.import_module("paddle_lite_amd.liteapi")
+
+
+@pytest.fixture(scope="module")
+def wl(pkg):
+    return importlib.import_module("paddle_lite_amd.workloads")
+
+
+@pytest.fixture(scope="module")
+def mf(pkg):
+    return importlib.import_module("paddle_lite_amd.modelfile")
+
+
+def _check_params(lite, mf, tensors, ops, batch=2):
+    blob = mf.write_container(None, tensors, ops)
+    net = mf.fuse_reference(tensors, ops)
+    p = lite.Predictor(planner=True)
+    q = lite.Predictor(planner=True)
+    try:
+        p.load_model(blob, batch)
+        got = [g for g in p.graph_ops() if g[0] in ("conv2d", "depthwise_conv2d", "fc")]
+        want = [o for o in net["ops"] if o["op"] in ("conv2d", "depthwise_conv2d", "fc")]
+        assert len(got) == len(want)
+        negated = 0
+        for (typ, w, b, s, isc, act, coef), o in zip(got, want):
+            assert typ == o["op"], (typ, o["name"])
+            assert np.array_equal(w, o["w"].reshape(-1)), o["name"]
+            assert np.array_equal(b, o["bias"]), o["name"]            # fp32 bit for bit: same operations, same order
+            assert np.array_equal(s, o["w_scale"]), o["name"]
+            assert np.float32(isc) == np.float32(o["in_scale"]), o["name"]
+            if typ != "fc":
+                assert act == o["act"] and np.float32(coef) == np.float32(o["act_coef"]), o["name"]
+        plan_loaded = p.graph_plan()
+        importlib.import_module("paddle_lite_amd.workloads").emit_graph(q, net, batch)
+        assert plan_loaded == q.graph_plan()
+    finally:
+        p.close()
+        q.close()
+    return net, blob
+
+
+def test_container_round_trip_mobilenet_v1(lite, mf):
+    tensors, ops = mf.slim_mobilenet_v1(res=64, classes=100)
+    net, blob = _check_params(lite, mf, tensors, ops)
+    # quant_dequant_op_fuser.cc:146-147: weight_scale = 127*127 / max_range / 127 per output channel; conv_bn_fuser.cc:
+    # x |alpha|, rows negated where the BN scale is negative
+    pw2 = [o for o in net["ops"] if o["name"] == "pw2"][0]
+    raw = tensors["pw2_weights"].astype(np.int8)
+    neg = tensors["pw2_bn_scale"] < 0
+    assert neg.any() and np.array_equal(pw2["w"][neg], -raw[neg]) and np.array_equal(pw2["w"][~neg], raw[~neg])
+    assert np.all(pw2["w_scale"] > 0) and len(set(pw2["w_scale"].tolist())) > 8  # per-channel after conv+bn
+    assert len(blob) > 100000 and blob[:8] == b"PLHIPM01"
+    assert [o["op"] for o in net["ops"]].count("depthwise_conv2d") == 13
+
+
+def test_container_round_trip_residual_patterns(lite, mf):
+    tensors, ops = mf.slim_residual_toy()
+    net, _ = _check_params(lite, mf, tensors, ops)
+    kinds = [(o["op"], o.get("act")) for o in net["ops"]]
+    assert ("add", "") in kinds and ("add", "relu") in kinds
+    assert any(o["op"] == "conv2d" and o["act"] == 2 and o["act_coef"] == 6.0 for o in net["ops"])  # relu6 threshold
+    assert any(o["op"] == "conv2d" and o["act"] == 0 for o in net["ops"])                            # linear conv
+
+
+def test_loader_rejects_garbage(lite, mf):
+    p = lite.Predictor(planner=True)
+    try:
+        with pytest.raises(lite.LiteError, match="PLHIPM01"):
+            p.load_model(b"not a model file at all....", 1)
+        tensors, ops = mf.slim_residual_toy()
+        blob = mf.write_container(None, tensors, ops)
+        with pytest.raises(lite.LiteError, match="truncated"):
+            p.load_model(blob[:len(blob) // 2], 1)
+    finally:
+        p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["mobilenet_v1", "residual_toy"])
+def test_loaded_program_equals_in_code_program_and_oracle(lite, wl, mf, plref, which):
+    if which == "mobilenet_v1":
+        tensors, ops = mf.slim_mobilenet_v1()
+        res = 224
+    else:
+        tensors, ops = mf.slim_residual_toy()
+        res = 32
+    blob = mf.write_container(None, tensors, ops)
+    net = mf.fuse_reference(tensors, ops)
+    img = np.random.default_rng(400).uniform(-1, 1, (2, 3, res, res)).astype(np.float32)
+    ref = graph_oracle.forward(plref, net, img)
+    a, b = lite.Predictor(0), lite.Predictor(0)
+    try:
+        a.load_model(blob, 2)
+        a.graph_set_fuse(False)
+        outs = a.graph_lower()
+        wl.emit_graph(b, net, 2, fuse=False)
+        b.graph_lower()
+        for p in (a, b):
+            p.set_input(net["input"], img)
+            p.run()
+        assert outs == [net["output"] + "/host"]
+        n = 0
+        for name, want in ref.items():
+            ga, gb = a.get_var(name, want.dtype), b.get_var(name, want.dtype)
+            assert np.array_equal(ga, gb), name  # loaded == in-code, every byte (fp32 included)
+            if want.dtype == np.int8:
+                assert np.array_equal(ga, want), name
+                n += 1
+            else:
+                np.testing.assert_allclose(ga, want, rtol=1e-5, atol=1e-5, err_msg=name)
+        assert n >= (28 if which == "mobilenet_v1" else 6)
+    finally:
+        a.close()
+        b.close()
