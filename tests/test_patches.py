@@ -1,0 +1,20 @@
+"""patches/*.patch (kHIP touch-points inside a real Paddle-Lite tree) must apply to the reference:
+tools/check_patches.sh runs `git apply --check` + `git apply` on scratch copies of the touched files.  The reference
+tree exists in the build container only; elsewhere the test is skipped."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_patches_apply_to_the_reference_tree():
+    if not os.path.isdir("/root/reference/lite"):
+        pytest.skip("reference tree not present on this machine")
+    p = subprocess.run([os.path.join(ROOT, "tools", "check_patches.sh")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out
+    assert "all 4 patches apply" in out
+    for name in os.listdir(os.path.join(ROOT, "patches")):
+        assert name.endswith(".patch") and ("applies: " + name) in out
