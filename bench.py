@@ -267,8 +267,12 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PLHIP_BENCH_FORCE_DIST=1: run the multi-rank code path (RCCL init, network broadcast, batch scatter, per-step
+    # all_gather, barriers) even with ONE rank: the only way to exercise the RCCL calls on a one-GPU box
+    use_dist = world > 1 or os.environ.get("PLHIP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -292,7 +296,7 @@ def main():
 
     # ---- network: rank 0 generates, RCCL broadcast over xGMI, every rank builds its predictors from the bytes ----
     net = build_net(wl, cfg, args.res) if rank == 0 else None
-    net = sharding.broadcast_net(net, dist, dev, rank, world)
+    net = sharding.broadcast_net(net, dist, dev, rank, world, force=use_dist)
     classes = net["shapes"][net["output"]][0] * net["shapes"][net["output"]][1] * net["shapes"][net["output"]][2]
 
     # ---- ONE global batch, generated on rank 0 and scattered (device to device over xGMI), resident before timing ----
@@ -309,7 +313,7 @@ def main():
     elif cfg["model"] == "conv":
         image = images
     else:
-        image = sharding.scatter_batch(images, global_batch, (c, h, w), dist, dev, rank, world)
+        image = sharding.scatter_batch(images, global_batch, (c, h, w), dist, dev, rank, world, force=use_dist)
         images = None
 
     P = max(1, args.inflight)
@@ -321,7 +325,7 @@ def main():
     # the coordinator (this thread) issues the collectives in step order on a stream that carries no compute, so every
     # rank issues them in the same order and the all_gather of step s overlaps the kernels of the following steps. ----
     DEPTH = 2 * P + 2
-    if world > 1:
+    if use_dist:
         local = [torch.zeros((max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
         gathered = [torch.empty((world * max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
         slot_free = [threading.Semaphore(1) for _ in range(DEPTH)]
@@ -356,7 +360,7 @@ def main():
                     e = engines[self.i]
                     for s_ in range(self.i, self.n, P):
                         e.run()
-                        if world > 1:
+                        if use_dist:
                             b = (self.base + s_) % DEPTH
                             slot_free[b].acquire()      # host: the collective that last read this slot has been ISSUED
                             e.wait_event(slot_event[b])  # device: ... and will have FINISHED before the copy below
@@ -381,7 +385,7 @@ def main():
         for f_ in flights:
             f_.n, f_.base = n, step_base[0]
             f_.cmd.release()
-        if world > 1:
+        if use_dist:
             for s_ in range(n):
                 f_ = flights[s_ % P]
                 while True:
@@ -410,13 +414,13 @@ def main():
             if f_.err:
                 raise f_.err
         step_base[0] += n
-        if world > 1 and not dry:
+        if use_dist and not dry:
             coord_stream.synchronize()  # every step's result is complete inside the timed region
 
     def sync_all():
         if not dry:
             torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize(dev)
@@ -427,13 +431,13 @@ def main():
     run_steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # ---- outside the timed region: the gathered result of the last step is complete and in rank-major image order ----
-    if world > 1 and last_gather[0] is not None:
+    if use_dist and last_gather[0] is not None:
         g_ = last_gather[0].float().cpu().numpy().reshape(world, max_rows, classes)
         for r in range(world):
             l_, h_ = sharding.shard_range(global_batch, r, world)
@@ -571,7 +575,7 @@ def main():
     for e in engines:
         if e is not None:
             e.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -48,11 +48,12 @@ def shard_range(global_batch, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_weights(W, dist, device, rank, world, src=0):
+def broadcast_weights(W, dist, device, rank, world, src=0, force=False):
     """Rank `src` passes its weight dict, the others None; everyone returns the same dict.
-    `dist` is torch.distributed (initialised); `device` the torch device of the transport buffer."""
+    `dist` is torch.distributed (initialised); `device` the torch device of the transport buffer.
+    force: run the collectives even with one rank (exercises the transport on a one-GPU box)."""
     import torch
-    if world == 1:
+    if world == 1 and not force:
         return W
     if rank == src:
         items, blob = pack_weights(W)
@@ -63,7 +64,9 @@ def broadcast_weights(W, dist, device, rank, world, src=0):
     items, nbytes = meta
     t = torch.from_numpy(blob).to(device) if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
     dist.broadcast(t, src=src)
-    return W if rank == src else unpack_weights(items, t.cpu().numpy())
+    if rank == src and not force:
+        return W
+    return unpack_weights(items, t.cpu().numpy())
 
 
 def all_gather_rows(local, dist, world):
@@ -156,10 +159,10 @@ def net_from_blob(skeleton, arrays):
     return net
 
 
-def broadcast_net(net, dist, device, rank, world, src=0):
+def broadcast_net(net, dist, device, rank, world, src=0, force=False):
     """Rank `src` passes the network, the others None: skeleton by broadcast_object_list, every weight / scale / bias
     array in ONE blob by dist.broadcast (RCCL over xGMI on GPUs)."""
-    if world == 1:
+    if world == 1 and not force:
         return net
     if rank == src:
         skeleton, arrays = net_to_blob(net)
@@ -167,16 +170,18 @@ def broadcast_net(net, dist, device, rank, world, src=0):
     else:
         arrays, meta = None, [None]
     dist.broadcast_object_list(meta, src=src)
-    arrays = broadcast_weights(arrays, dist, device, rank, world, src)
-    return net if rank == src else net_from_blob(meta[0], arrays)
+    arrays = broadcast_weights(arrays, dist, device, rank, world, src, force=force)
+    if rank == src and not force:
+        return net
+    return net_from_blob(meta[0], arrays)
 
 
-def scatter_batch(images, global_batch, sample_shape, dist, device, rank, world, src=0):
+def scatter_batch(images, global_batch, sample_shape, dist, device, rank, world, src=0, force=False):
     """One global batch generated on rank `src` -> every rank's contiguous shard [lo, hi) (shard_range; ragged sizes
     allowed: shards are padded to the largest one for the collective).  Returns a numpy array [hi - lo, ...]."""
     import torch
     lo, hi = shard_range(global_batch, rank, world)
-    if world == 1:
+    if world == 1 and not force:
         return np.ascontiguousarray(images[lo:hi])
     rows = max(shard_range(global_batch, r, world)[1] - shard_range(global_batch, r, world)[0] for r in range(world))
     recv = torch.empty((rows,) + tuple(sample_shape), dtype=torch.float32, device=device)
