@@ -236,6 +236,11 @@ def main():
     if args.gpus != world:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
+    # stdout carries exactly ONE line, the JSON record: everything else that libraries print there (RCCL's version banner,
+    # c10d notices) is sent to stderr by pointing fd 1 at fd 2 and keeping the real stdout aside
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     cfg = dict(CONFIGS[args.config])
     if cfg["model"] == "conv" and world > 1:
         sys.stderr.write("bench.py: config c2 is a single-GPU op benchmark\n")
@@ -567,8 +572,8 @@ def main():
             "whole_graph_frac_of_i8_mfma_peak": round(val * ops_per_img / 1e12 / MFMA_I8_PEAK_TOPS, 4),
             "single_stream": serial, "roofline": roof, "kernels": fam_out, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
-        sys.stdout.flush()
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     for f_ in flights:
         f_.alive = False
         f_.cmd.release()
