@@ -1042,7 +1042,41 @@ __global__ void pad_input_i8_kernel(PadArgs a) {
   }
 }
 
+// Phase-split padded copy for the stride-2 implicit GEMM: xp[plane][p][q][y][x] = padded[plane][2y + p][2x + q].
+// One thread = one aligned dword (4 consecutive x of one phase row): 4 source bytes at stride 2.
+__global__ void pad_input_phase2_i8_kernel(PadArgs a) {
+  const long nq = a.total >> 2;
+  const int pwq = a.pw >> 2;  // launcher: phase rows are padded to a multiple of 4 columns
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    const int xq = (int)(q % pwq);
+    long t = q / pwq;
+    const int y = (int)(t % a.ph);
+    t /= a.ph;
+    const int ph = (int)(t & 3);
+    const long plane = t >> 2;
+    uint32_t v = 0;
+    if (plane < a.planes) {
+      const int iy = 2 * y + (ph >> 1) - a.pt;
+      if (iy >= 0 && iy < a.h) {
+        const int8_t* row = a.x + ((size_t)plane * a.h + iy) * a.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ix = 2 * (4 * xq + i) + (ph & 1) - a.pl;
+          if (ix >= 0 && ix < a.w) v |= (uint32_t)(uint8_t)row[ix] << (8 * i);
+        }
+      }
+    }
+    reinterpret_cast<uint32_t*>(a.xp)[q] = v;
+  }
+}
+
 void launch_pad_input(const PadArgs& a, hipStream_t s) {
+  if (a.stride == 2) {
+    long blocks2 = ((a.total >> 2) + 255) / 256;
+    if (blocks2 > 65536) blocks2 = 65536;
+    hipLaunchKernelGGL(pad_input_phase2_i8_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, a);
+    return;
+  }
   long blocks = ((a.total >> 2) + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(pad_input_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);

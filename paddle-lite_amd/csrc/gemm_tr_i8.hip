@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
   PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.K); PLHIP_PRELOAD(g.KS); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP);
   PLHIP_PRELOAD(g.NB); PLHIP_PRELOAD(g.x_bstride); PLHIP_PRELOAD(g.y_bstride); PLHIP_PRELOAD(g.MT); PLHIP_PRELOAD(g.NT);
   PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg);
-  PLHIP_PRELOAD(g.im_kw); PLHIP_PRELOAD(g.im_khkw); PLHIP_PRELOAD(g.im_c); PLHIP_PRELOAD(g.im_ph); PLHIP_PRELOAD(g.im_pw); PLHIP_PRELOAD(g.im_oh);
+  PLHIP_PRELOAD(g.im_kw); PLHIP_PRELOAD(g.im_khkw); PLHIP_PRELOAD(g.im_c); PLHIP_PRELOAD(g.im_ph); PLHIP_PRELOAD(g.im_pw); PLHIP_PRELOAD(g.im_oh); PLHIP_PRELOAD(g.im_s);
   extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // NS * SLOT, ONE LDS object
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
     const uint8_t* asrc;
     if (implicit) {
       const int bi_ = pb / g.im_oh, oh = pb - bi_ * g.im_oh;
-      asrc = reinterpret_cast<const uint8_t*>(g.x) + ((size_t)bi_ * g.im_c * g.im_ph + oh) * g.im_pw + pcol;
+      const int nph = g.im_s * g.im_s;  // phase planes per channel (stride 2: 4)
+      asrc = reinterpret_cast<const uint8_t*>(g.x) + ((size_t)bi_ * g.im_c * nph * g.im_ph + oh) * g.im_pw + pcol;
       kc[q] = prow / g.im_khkw;
       krs[q] = prow - kc[q] * g.im_khkw;
     } else {
@@ -248,7 +249,10 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
         // rows past K meet zero-padded weights: any in-bounds address will do (the last real tap)
         const int cc = kc[q] < g.im_c ? kc[q] : g.im_c - 1, rs = kc[q] < g.im_c ? krs[q] : g.im_khkw - 1;
         const int r = (rs * ((65536 + g.im_kw - 1) / g.im_kw)) >> 16;  // rs / kw, exact for rs < 128, kw <= 11
-        const size_t off = ((size_t)cc * g.im_ph + r) * g.im_pw + (rs - r * g.im_kw);
+        const int sx = rs - r * g.im_kw;
+        // stride 2: tap (r, sx) lives in phase plane (r & 1, sx & 1) at row / column offset (r >> 1, sx >> 1)
+        const size_t off = g.im_s == 1 ? ((size_t)cc * g.im_ph + r) * g.im_pw + sx
+                                       : ((size_t)(cc * 4 + (r & 1) * 2 + (sx & 1)) * g.im_ph + (r >> 1)) * g.im_pw + (sx >> 1);
         kc[q] += kc_step;
         krs[q] += krs_step;
         if (krs[q] >= g.im_khkw) {

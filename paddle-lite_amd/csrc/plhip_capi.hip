@@ -60,8 +60,22 @@ static bool implicit_gemm_disabled() {  // PLHIP_IMPLICIT_GEMM=0: A/B runs again
   }
   return v == 1;
 }
+// dims of the padded copy of the implicit-GEMM route: stride 1 the padded plane; stride 2 ONE of the 4 phase planes
+// (rows / columns 2y + p, 2x + q of the padded plane), its rows padded to a multiple of 4 columns
+static void padded_dims(const plhip_conv_desc* d, int* ph, int* pw) {
+  const int PH = d->h + d->pad[0] + d->pad[1], PW = d->w + d->pad[2] + d->pad[3];
+  if (d->stride[0] == 2) {
+    *ph = (PH + 1) / 2;
+    *pw = rup((PW + 1) / 2, 4);
+  } else {
+    *ph = PH;
+    *pw = PW;
+  }
+}
 static size_t padded_input_bytes(const plhip_conv_desc* d) {  // + slack: the last 16-byte pieces run past the last row
-  const size_t b = (size_t)d->n * d->cin * (d->h + d->pad[0] + d->pad[1]) * (d->w + d->pad[2] + d->pad[3]);
+  int ph, pw;
+  padded_dims(d, &ph, &pw);
+  const size_t b = (size_t)d->n * d->cin * (d->stride[0] == 2 ? 4 : 1) * ph * pw;
   return ((b + 3) & ~(size_t)3) + 64;
 }
 
@@ -101,15 +115,18 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   // dense k x k stride-1 convs whose GEMM fits the LDS-DMA ring kernel (64-row wave tiles: M > 128, 32-row tiles: 96 < M <=
   // 128 with K >= 256) skip the im2col buffer: implicit GEMM on a zero-padded copy of the input (1.08x the input
   // instead of kh*kw x: BASELINE config #2 spent 128 of 149 us writing its 57.8 MB im2col buffer)
-  if (g->impl == IMPL_IM2COL_GEMM && d->groups == 1 && d->stride[0] == 1 && d->stride[1] == 1 && d->dil[0] == 1 &&
-      d->dil[1] == 1 && d->kw <= 11 && d->kh * d->kw <= 121 && !implicit_gemm_disabled()) {
-    const size_t padded = (size_t)d->n * d->cin * (d->h + d->pad[0] + d->pad[1]) * (d->w + d->pad[2] + d->pad[3]);
+  const bool s1 = d->stride[0] == 1 && d->stride[1] == 1, s2 = d->stride[0] == 2 && d->stride[1] == 2;
+  if (g->impl == IMPL_IM2COL_GEMM && d->groups == 1 && (s1 || s2) && d->dil[0] == 1 && d->dil[1] == 1 && d->kw <= 11 &&
+      d->kh * d->kw <= 121 && !implicit_gemm_disabled()) {
+    const size_t padded = padded_input_bytes(d);
     const bool fits = padded < ((size_t)1 << 31) - 4096 && (size_t)d->n * g->oh * rup(g->ow, 16) < ((size_t)1 << 31) - 256;
     if (plhip::gemm_tr_enabled()) {
-      // transposed-read ring kernel: any M > 32, K >= 97, and output rows down to 7 columns (one start-aligned 16-byte
-      // chunk per row; 14x14 and 7x7 planes of ResNet50's last stages)
-      if (fits && g->Mg > 32 && g->KS >= 4 && g->ow >= 7) g->impl = IMPL_IMPLICIT_GEMM;
-    } else {
+      // transposed-read ring kernel: any M > 32, K >= 97, output rows down to 7 columns (one start-aligned 16-byte
+      // chunk per row: the 14x14 and 7x7 planes of ResNet50's last stages), and stride 2 on a phase-split padded copy
+      // (ResNet50's 7x7 stem and its three 3x3 downsampling convs); a 1x1 stride-2 conv would use one phase plane of
+      // four: it keeps the (strided-copy) im2col route
+      if (fits && g->Mg > 32 && g->KS >= 4 && g->ow >= 7 && !(s2 && d->kh * d->kw == 1)) g->impl = IMPL_IMPLICIT_GEMM;
+    } else if (s1) {
       const int ma = (g->MA == 2 && g->Mg <= 128 && g->Mg > 64) ? 1 : g->MA;  // launch_gemm_i8's tile choice
       const int mt = cdiv(g->Mg, 32 * ma);
       if (fits && g->ow >= 16 && mt >= 4 && g->KS >= 4 && (ma == 2 || g->KS >= 8)) g->impl = IMPL_IMPLICIT_GEMM;
@@ -319,8 +336,10 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     const size_t need = padded_input_bytes(d);
     if (!workspace || workspace_bytes < need || !aligned(workspace, 4))
       return fail(ctx, PLHIP_ERR_WORKSPACE, "plhip_conv2d_int8: padded-input workspace missing, too small or unaligned");
-    const int PH = d->h + d->pad[0] + d->pad[1], PW = d->w + d->pad[2] + d->pad[3];
+    int PH, PW;
+    padded_dims(d, &PH, &PW);
     plhip::PadArgs pa;
+    pa.stride = d->stride[0];
     pa.x = x;
     pa.xp = (int8_t*)workspace;
     pa.planes = d->n * d->cin;
@@ -350,6 +369,7 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     a.act = d->act;
     a.alpha = d->act_alpha;
     a.im_kw = d->kw; a.im_khkw = d->kh * d->kw; a.im_c = d->cin; a.im_ph = PH; a.im_pw = PW; a.im_oh = g.oh;
+    a.im_s = d->stride[0];
     a.res = t_res; a.res_relu = t_relu; a.y2 = t_y2; a.inv_scale2 = t_inv;
     const bool vec_store_i = (g.ow & 3) == 0 && aligned(y, 4 * esz_i) && aligned(t_res, 16) && aligned(t_y2, 4);
     plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store_i, true, ctx->stream);
@@ -427,6 +447,7 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     a.act = d->act;
     a.alpha = d->act_alpha;
     a.im_kw = a.im_khkw = a.im_c = a.im_ph = a.im_pw = a.im_oh = 0;
+    a.im_s = 1;
     plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store, aligned_loads, ctx->stream);
     LAUNCHCHK(ctx, "gemm_i8");
   }

@@ -35,12 +35,17 @@ struct GemmArgs {
   // Then an "image" of the column space is one output row (NB = batch * OH, HWX = OW) and K-row k = (c, r, s) of it
   // starts at  x + ((b*C + c)*PH + oh + r)*PW + s : contiguous bytes, so the B tile still moves as 16-byte pieces.
   int im_kw, im_khkw, im_c, im_ph, im_pw, im_oh;
+  // stride of the implicit conv (1 or 2; transposed-read kernel only).  Stride 2: the padded copy is PHASE-SPLIT, plane
+  // (c, p, q) holds padded[c][2y + p][2x + q] (im_ph x im_pw each), so that tap (r, s) of output (oh, ow) is byte
+  // ((c*4 + (r&1)*2 + (s&1)) * im_ph + oh + (r>>1)) * im_pw + ow + (s>>1): contiguous in ow again.
+  int im_s;
 };
 
 struct PadArgs {
   const int8_t* x;  // [planes][h][w]
-  int8_t* xp;       // [planes][ph][pw] + slack, zero border
+  int8_t* xp;       // [planes][ph][pw] + slack, zero border; stride 2: [planes][2][2][ph][pw] phase planes
   int planes, h, w, ph, pw, pt, pl;
+  int stride;       // 1, or 2 = phase-split copy (ph, pw are then the phase plane's dims)
   long total;       // bytes of xp to write (multiple of 4: planes*ph*pw rounded up + slack)
 };
 void launch_pad_input(const PadArgs& a, hipStream_t s);

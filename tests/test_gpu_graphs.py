@@ -242,6 +242,43 @@ def test_implicit_gemm_short_rows_and_small_m(gpu_ctx, plref, pkg):
                 np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6)
 
 
+def test_implicit_gemm_stride2_phase_split(gpu_ctx, plref, pkg):
+    """Dense stride-2 convs (ResNet50's 7x7 stem and 3x3 downsampling convs) run as implicit GEMM on a PHASE-SPLIT padded
+    copy (4 planes per channel: rows / columns 2y+p, 2x+q), so each tap row is contiguous in ow again.  Odd and even
+    extents, asymmetric pads, 3x3 / 5x5 / 7x7, short output rows; int32 accumulators, int8 and fp32 outputs."""
+    capi = pkg.capi
+    rng = np.random.default_rng(331)
+    cases = [  # n, cin, cout, h, w, k, pads(t, b, l, r)
+        (2, 3, 64, 64, 64, 7, (3, 3, 3, 3)),       # the stem's shape class (K = 147)
+        (2, 32, 64, 28, 28, 3, (1, 1, 1, 1)),      # res3a/4a/5a branch2b class
+        (3, 16, 48, 15, 17, 3, (1, 1, 1, 1)),      # odd extents
+        (2, 16, 40, 14, 14, 3, (0, 1, 0, 1)),      # asymmetric pads, 7-column output rows
+        (1, 8, 96, 33, 31, 5, (2, 2, 2, 2)),
+        (2, 128, 128, 56, 56, 3, (1, 1, 1, 1)),    # res3a_branch2b itself
+    ]
+    for (n, cin, cout, h, wd, k, pads) in cases:
+        x = rng.integers(-127, 128, (n, cin, h, wd)).astype(np.int8)
+        w = rng.integers(-127, 128, (cout, cin, k, k)).astype(np.int8)
+        bias = rng.uniform(-1, 1, cout).astype(np.float32)
+        wsc = ((1 + np.arange(cout) % 5) / 127.0 / 4.0).astype(np.float32)
+        d = capi.conv_desc(n, cin, h, wd, cout, k, k, pads, (2, 2), (1, 1), 1, capi.ACT_RELU, 0.0)
+        assert capi.load().plhip_conv_impl_name(d).decode().startswith("conv_implicit_gemm"), (cin, cout, h, k)
+        s = plref.shape(n, cin, h, wd, cout, k, k, pads, (2, 2), (1, 1), 1)
+        acc_ref = plref.conv2d_acc(s, x, w)
+        assert np.array_equal(gpu_ctx.conv2d(d, x, w, None, None, capi.OUT_I32), acc_ref), (cin, cout, h, k)
+        for int8_out, kind in ((1, capi.OUT_I8), (0, capi.OUT_F32)):
+            sc, bi, al = plref.fold_scales(int8_out, 1 / 127.0, wsc, cin * k * k / 127.0, bias, cout, 1, 0.0)
+            y = gpu_ctx.conv2d(d, x, w, sc, bi, kind)
+            ref = plref.epilogue(acc_ref, sc, bi, 1, al, bool(int8_out))
+            if int8_out:
+                assert np.array_equal(y, ref), (cin, cout, h, k)
+            else:
+                np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6)
+    # a 1x1 stride-2 conv would read one phase plane of four: it keeps the strided-copy GEMM route
+    d = capi.conv_desc(2, 256, 56, 56, 512, 1, 1, (0, 0, 0, 0), (2, 2), (1, 1), 1, capi.ACT_NONE, 0.0)
+    assert not capi.load().plhip_conv_impl_name(d).decode().startswith("conv_implicit_gemm")
+
+
 @pytest.mark.parametrize("which", ["resnet50", "mobilenet_v2"])
 def test_fused_programs_equal_the_oracle_graph(lite, wl, plref, which):
     """Default (fused) lowering: conv + residual add + relu + calib in one launch, int8 max pool behind the stem.  Every
