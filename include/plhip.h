@@ -131,7 +131,10 @@ plhip_status plhip_depthwise_conv_int8(plhip_ctx* ctx, const plhip_conv_desc* d,
  * dw: descriptor of the depthwise conv (groups == cin == cout, 3x3, stride 1|2, dilation 1); dw_scale / dw_bias: its
  * folded int8-out scale / bias; pw_cout, pw_w_packed (from plhip_pack_conv_weights of the 1x1 conv), pw_scale / pw_bias,
  * pw_act / pw_alpha describe the pointwise conv; y: [n, pw_cout, oh, ow] of kind `out`.
- * Returns PLHIP_ERR_UNSUPPORTED when the shape is outside the fused path (caller falls back to the two calls). */
+ * Returns PLHIP_ERR_UNSUPPORTED when the shape is outside the fused path (caller falls back to the two calls):
+ * 3x3, stride 1 | 2, dilation 1, <= 1024 channels, a 128..1024-column tile touching <= 4 images, and 4 K-steps of the
+ * tile's staged input rows (32 channels each) fitting the CU's LDS — plhip_dwpw_fused_supported answers that up front. */
+int plhip_dwpw_fused_supported(const plhip_conv_desc* dw, int pw_cout, plhip_out_kind out);
 plhip_status plhip_dwpw_fused_int8(plhip_ctx* ctx, const plhip_conv_desc* dw, const int8_t* x, const int8_t* dw_w_oihw,
                                    const float* dw_scale, const float* dw_bias, int pw_cout, const void* pw_w_packed,
                                    const float* pw_scale, const float* pw_bias, int pw_act, float pw_alpha, void* y,

@@ -22,7 +22,7 @@ EXPORTS = [
     "plhip_memcpy_d2h", "plhip_memcpy_d2d", "plhip_memset", "plhip_stream_sync", "plhip_event_create",
     "plhip_event_record", "plhip_event_elapsed_ms", "plhip_event_destroy",
     "plhip_conv_packed_weight_bytes", "plhip_pack_conv_weights", "plhip_conv_workspace_bytes",
-    "plhip_conv2d_int8", "plhip_conv2d_int8_fused", "plhip_conv_impl_name", "plhip_depthwise_conv_int8", "plhip_dwpw_fused_int8",
+    "plhip_conv2d_int8", "plhip_conv2d_int8_fused", "plhip_conv_impl_name", "plhip_depthwise_conv_int8", "plhip_dwpw_fused_int8", "plhip_dwpw_fused_supported",
     "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
     "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
     "plhip_pool2d_f32", "plhip_pool2d_max_i8", "plhip_elementwise_add_f32", "plhip_selftest",
@@ -109,6 +109,8 @@ def load():
     L.plhip_conv_impl_name.restype = C.c_char_p
     L.plhip_depthwise_conv_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32]
     L.plhip_dwpw_fused_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, vp, i32]
+    L.plhip_dwpw_fused_supported.argtypes = [C.POINTER(ConvDesc), i32, i32]
+    L.plhip_dwpw_fused_supported.restype = i32
     L.plhip_fc_packed_weight_bytes.argtypes = [i32, i32]
     L.plhip_fc_packed_weight_bytes.restype = sz
     L.plhip_pack_fc_weights.argtypes = [vp, i32, i32, vp, vp]

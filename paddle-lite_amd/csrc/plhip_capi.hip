@@ -548,40 +548,55 @@ plhip_status plhip_depthwise_conv_int8(plhip_ctx* ctx, const plhip_conv_desc* d,
 }
 
 // ------------------------------------------------------------------ fused depthwise -> pointwise
+// geometry + launch plan of the fused pair; false: not a depthwise 3x3 the fused kernel takes (the caller runs two kernels)
+static bool dwpw_plan(const plhip_conv_desc* dw, int pw_cout, plhip_out_kind out, plhip::FusedArgs* a, const char** why) {
+  ConvGeom g;
+  *why = "bad depthwise descriptor";
+  if (!dw || pw_cout < 1 || !conv_geom(dw, &g)) return false;
+  *why = "first conv must be depthwise";
+  if (dw->groups != dw->cin || dw->cin != dw->cout) return false;
+  *why = "tensor too large";
+  if ((size_t)pw_cout * g.N >= ((size_t)1 << 31) || (size_t)dw->cin * dw->h * dw->w >= ((size_t)1 << 31)) return false;
+  memset(a, 0, sizeof(*a));
+  a->dw_act = dw->act;
+  a->dw_alpha = dw->act_alpha;
+  a->n = dw->n; a->C = dw->cin; a->h = dw->h; a->w = dw->w; a->oh = g.oh; a->ow = g.ow;
+  a->pt = dw->pad[0]; a->pl = dw->pad[2]; a->stride = dw->stride[0];
+  a->pw.M = pw_cout;
+  a->pw.K = dw->cin;
+  a->pw.KS = cdiv(dw->cin, 32);
+  a->pw.HWY = g.N;
+  a->pw.y_bstride = (size_t)pw_cout * g.N;
+  *why = "shape outside the fused path";
+  return plhip::fused_dwpw_plan(a, dw->kh, dw->kw, dw->stride[0], dw->stride[1], dw->dil[0], dw->dil[1], (int)out);
+}
+
+int plhip_dwpw_fused_supported(const plhip_conv_desc* dw, int pw_cout, plhip_out_kind out) {
+  plhip::FusedArgs a;
+  const char* why;
+  return dwpw_plan(dw, pw_cout, out, &a, &why) ? 1 : 0;
+}
+
 plhip_status plhip_dwpw_fused_int8(plhip_ctx* ctx, const plhip_conv_desc* dw, const int8_t* x, const int8_t* dw_w_oihw,
                                    const float* dw_scale, const float* dw_bias, int pw_cout, const void* pw_w_packed,
                                    const float* pw_scale, const float* pw_bias, int pw_act, float pw_alpha, void* y,
                                    plhip_out_kind out) {
-  ConvGeom g;
-  if (!ctx || !x || !dw_w_oihw || !dw_scale || !pw_w_packed || !y || pw_cout < 1)
+  if (!ctx || !dw || !x || !dw_w_oihw || !dw_scale || !pw_w_packed || !y || pw_cout < 1)
     return fail(ctx, PLHIP_ERR_INVALID, "plhip_dwpw_fused_int8: null / bad argument");
-  if (!conv_geom(dw, &g)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_dwpw_fused_int8: bad depthwise descriptor");
-  if (dw->groups != dw->cin || dw->cin != dw->cout)
-    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_dwpw_fused_int8: first conv must be depthwise");
   if (out != PLHIP_OUT_I32_ACC && !pw_scale) return fail(ctx, PLHIP_ERR_INVALID, "plhip_dwpw_fused_int8: pw_scale required");
-  if (!plhip::fused_dwpw_supported(dw->cin, dw->kh, dw->kw, dw->stride[0], dw->stride[1], dw->dil[0], dw->dil[1], dw->pad[2], g.ow))
-    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_dwpw_fused_int8: shape outside the fused path");
-  if ((size_t)pw_cout * g.N >= ((size_t)1 << 31) || (size_t)dw->cin * dw->h * dw->w >= ((size_t)1 << 31))
-    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_dwpw_fused_int8: tensor too large");
   plhip::FusedArgs a;
-  memset(&a, 0, sizeof(a));
+  const char* why;
+  if (!dwpw_plan(dw, pw_cout, out, &a, &why)) {
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_dwpw_fused_int8: %s", why);
+  }
   a.x = x;
   a.dw_w = dw_w_oihw;
   a.dw_scale = dw_scale;
   a.dw_bias = dw_bias;
-  a.dw_act = dw->act;
-  a.dw_alpha = dw->act_alpha;
-  a.n = dw->n; a.C = dw->cin; a.h = dw->h; a.w = dw->w; a.oh = g.oh; a.ow = g.ow;
-  a.pt = dw->pad[0]; a.pl = dw->pad[2]; a.stride = dw->stride[0];
   a.pw.wp = (const int8_t*)pw_w_packed;
   a.pw.y = y;
   a.pw.scale = pw_scale;
   a.pw.bias = pw_bias;
-  a.pw.M = pw_cout;
-  a.pw.K = dw->cin;
-  a.pw.KS = cdiv(dw->cin, 32);
-  a.pw.HWY = g.N;
-  a.pw.y_bstride = (size_t)pw_cout * g.N;
   a.pw.act = pw_act;
   a.pw.alpha = pw_alpha;
   plhip::launch_fused_dwpw(a, (int)out, ctx->stream);
@@ -732,10 +747,15 @@ plhip_status plhip_selftest(plhip_ctx* ctx) {
 namespace plhip {
 int debug_read_stamps(void* dst, size_t bytes);
 int debug_read_tr_stamps(void* dst, size_t bytes);
+int debug_read_fz_stamps(void* dst, size_t bytes);
 }
 extern "C" int plhip_debug_read_tr_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();
   return plhip::debug_read_tr_stamps(dst_host, bytes);
+}
+extern "C" int plhip_debug_read_fz_stamps(void* dst_host, size_t bytes) {
+  (void)hipDeviceSynchronize();
+  return plhip::debug_read_fz_stamps(dst_host, bytes);
 }
 extern "C" int plhip_debug_read_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();

@@ -90,10 +90,16 @@ struct FusedArgs {
   int dw_act;
   float dw_alpha;
   int n, C, h, w, oh, ow, pt, pl, stride;
-  int R;                  // output rows (of the flattened batch x OH space) per tile, set by the launcher
-  GemmArgs pw;            // wp, y, scale, bias, M, KS, HWY (= oh*ow), y_bstride, act, alpha
+  // launch plan (fused_dwpw_plan): quads per output row, quads of the column space, the staged-input ring
+  int wn;                   // column groups (of 128) per workgroup: 8 / 4 / 2 / 1; WM = 8 / wn slices of 64 output channels
+  int owq;
+  long NQ;
+  int slot_bytes, ni, pwd;  // bytes / DMA instructions of one K-step of staged input, DMA instructions per wave
+  size_t raw_bytes;         // dynamic LDS (the LDS-DMA ring)
+  GemmArgs pw;              // wp, y, scale, bias, M, KS, HWY (= oh*ow), y_bstride, act, alpha
 };
-bool fused_dwpw_supported(int C, int kh, int kw, int sh, int sw, int dh, int dw, int pl, int ow);
+// fills the plan from (n, C, h, w, oh, ow, pt, pl, stride, pw.M); false = shape outside the fused path
+bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int dw, int out);
 void launch_fused_dwpw(const FusedArgs& a, int out, hipStream_t s);
 
 void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);

@@ -1,10 +1,7 @@
-mkdir -p gpurun_out/r2b
-timeout -k 5 200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_graphs.py -q -m gpu -x 2>&1 | tail -3
-for tr in 1 0; do
-echo "== PLHIP_GEMM_TR=$tr"
-PLHIP_GEMM_TR=$tr timeout -k 5 60 python tools/c2bench.py | head -1
-PLHIP_GEMM_TR=$tr timeout -k 5 60 python tools/c2bench.py --n 256 --cin 64 --cout 64 --hw 56 | head -1
-PLHIP_GEMM_TR=$tr timeout -k 5 60 python tools/c2bench.py --n 256 --cin 128 --cout 128 --hw 28 | head -1
-PLHIP_GEMM_TR=$tr timeout -k 5 60 python tools/c2bench.py --n 256 --cin 256 --cout 256 --hw 14 | head -1
-PLHIP_GEMM_TR=$tr timeout -k 5 60 python tools/c2bench.py --n 256 --cin 512 --cout 512 --hw 7 | head -1
+#!/bin/bash
+# scratch: timing experiments of the fused kernel
+mkdir -p gpurun_out/fz
+for d in 0 1 2 4 5 6 7; do
+  echo "== PLHIP_FUSED_DEBUG=$d"
+  PLHIP_FUSED_DEBUG=$d timeout -k 10 200 python tools/opbench.py fused --batch 128 2>&1 | grep -E "dw2 |dw4 |dw6 |dw8 |dw13|dw14|fused total"
 done

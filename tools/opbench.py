@@ -99,14 +99,23 @@ def main():
                 out_kind = capi.OUT_F32 if pn == "pw14" else capi.OUT_I8
                 esz = 4 if out_kind == capi.OUT_F32 else 1
                 dy = ctx.malloc(B * m * hmid * hmid * esz)
-                fn = lambda: ctx.check(L.plhip_dwpw_fused_int8(ctx.h, C.byref(d), dx, dwd, dsd, None, m, dwp, dsp, None,
-                                                               capi.ACT_RELU, 0.0, dy, out_kind), "fused")
+                how = "fused"
+                if L.plhip_dwpw_fused_supported(C.byref(d), m, out_kind):
+                    fn = lambda: ctx.check(L.plhip_dwpw_fused_int8(ctx.h, C.byref(d), dx, dwd, dsd, None, m, dwp, dsp, None,
+                                                                   capi.ACT_RELU, 0.0, dy, out_kind), "fused")
+                else:  # outside the fused path: what the predictor runs instead, the two kernels
+                    how = "2-krn"
+                    dmid = ctx.malloc(B * c * hmid * hmid)
+
+                    def fn():
+                        ctx.check(L.plhip_depthwise_conv_int8(ctx.h, C.byref(d), dx, dwd, dsd, None, dmid, capi.OUT_I8), "dw")
+                        ctx.check(L.plhip_conv2d_int8(ctx.h, C.byref(dp), dmid, dwp, dsp, None, dy, out_kind, None, 0), "pw")
                 ms = time_op(ctx, fn, args.reps)
                 byts = B * (c * hin * hin + m * hmid * hmid * esz)
                 macs = B * hmid * hmid * (m * c + 9 * c)
                 ftot += ms
-                print("%-4s+%-5s fused %4d->%4d %3dx%-3d s%d  %8.2f us  %7.1f GB/s  %7.1f TOP/s" % (
-                    dn, pn, c, m, hin, hin, s, ms * 1e3, byts / ms / 1e6, 2 * macs / ms / 1e9), flush=True)
+                print("%-4s+%-5s %s %4d->%4d %3dx%-3d s%d  %8.2f us  %7.1f GB/s  %7.1f TOP/s" % (
+                    dn, pn, how, c, m, hin, hin, s, ms * 1e3, byts / ms / 1e6, 2 * macs / ms / 1e9), flush=True)
                 for q in list(ctx._allocs):
                     ctx.free(q)
         print("fused total %.2f us" % (ftot * 1e3))
