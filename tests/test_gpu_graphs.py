@@ -352,7 +352,10 @@ def test_int8_max_pool_commutes_with_calib(gpu_ctx, plref):
     a = plref.calib_f32_to_i8(plref.pool2d(x, "max", (3, 3), (2, 2), (1, 1, 1, 1)), scale)
     b = gpu_ctx.pool2d(plref.calib_f32_to_i8(x, scale), "max", (3, 3), (2, 2), (1, 1, 1, 1))
     assert b.dtype == np.int8 and np.array_equal(a, b)
-    for (h, w, k, s, pads) in [(7, 9, 2, 2, (0, 0, 0, 0)), (13, 17, 3, 2, (0, 1, 1, 2)), (6, 6, 3, 3, (1, 1, 1, 1))]:
-        xi = rng.integers(-127, 128, (2, 3, h, w)).astype(np.int8)
+    # 3x3 stride 2 has its own kernel (12-byte row windows, -128 outside the image): odd extents, every pad mix, tiny planes
+    for (h, w, k, s, pads) in [(7, 9, 2, 2, (0, 0, 0, 0)), (13, 17, 3, 2, (0, 1, 1, 2)), (6, 6, 3, 3, (1, 1, 1, 1)),
+                               (15, 15, 3, 2, (1, 1, 1, 1)), (8, 4, 3, 2, (1, 0, 1, 0)), (3, 4, 3, 2, (1, 1, 1, 1)),
+                               (9, 33, 3, 2, (0, 0, 0, 0)), (28, 30, 3, 2, (1, 1, 0, 1))]:
+        xi = rng.integers(-128, -100, (2, 3, h, w)).astype(np.int8) if h == 15 else rng.integers(-127, 128, (2, 3, h, w)).astype(np.int8)
         want = plref.pool2d(xi.astype(np.float32), "max", (k, k), (s, s), pads).astype(np.int8)
         assert np.array_equal(gpu_ctx.pool2d(xi, "max", (k, k), (s, s), pads), want)
