@@ -447,18 +447,24 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw_kernel(FusedArgs a) {
     }
     issue_raw(ks + L + 2);
     issue_w(ks + L + 1, wset[(CS + L + 1) % (L + 2)]);
+    auto multiply = [&]() __attribute__((always_inline)) {
+      if (!(dbg & 2)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const v4i av = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+            acc[t][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wset[CS][u], acc[t][u], 0, 0, 0);
+          }
+      } else {
+        acc[0][0][0] += lo[0][0] ^ lo[1][1] ^ hi[2][0] ^ hi[3][1] ^ wset[CS][0][0] ^ wset[CS][1][3];
+      }
+    };
+    // MFMAs FIRST: a wave sits in its 8 MFMAs for ~256 cycles while the matrix pipe is busy; the other wave of the SIMD
+    // queues behind it, so the two skew by one MFMA block and each one's depthwise VALU work then overlaps the other's
+    // MFMAs (produce-first made both waves compete for the VALU and then both queue for the matrix pipe)
+    multiply();
     if (ks + 1 < KS) produce(ks + 1, nxt);
-    if (!(dbg & 2)) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const v4i av = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
-          acc[t][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wset[CS][u], acc[t][u], 0, 0, 0);
-        }
-    } else {
-      acc[0][0][0] += lo[0][0] ^ lo[1][1] ^ hi[2][0] ^ hi[3][1] ^ wset[CS][0][0] ^ wset[CS][1][3];
-    }
   };
   static_assert(L + 2 == 4 && D == 4, "the loop below is unrolled for 4 weight sets / ring slots");
   for (int ks = 0; ks < KS; ks += 4) {
@@ -500,18 +506,21 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw_kernel(FusedArgs a) {
       // OW % 4 != 0: the quad's dword goes to its COMPACT byte offset (flat pixel index relative to the wave's first
       // pixel), only its valid bytes, as naturally aligned 16-bit (even OW) / 8-bit writes
       const uint32_t stg_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stg;
-      const int P0 = fz_pixel((int)Qw, owq, a.ow);
+      const int xq0 = (int)Qw % owq;  // wave-uniform
+      const float inv_owq = 1.0f / (float)owq;
       const float hi2 = g.act == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
       const float lo2 = (g.act == ACT_RELU || g.act == ACT_RELU6) ? 0.f : -254.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         int co[4], room[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {  // quad 8t + 4h + e of the wave's 32
-          const int Q = (int)Qw + 8 * t + 4 * h + e;
-          const int xq = Q % owq;
-          co[e] = fz_pixel(Q, owq, a.ow) - P0;
-          room[e] = Q > Qe ? 0 : (a.ow - 4 * xq < 4 ? a.ow - 4 * xq : 4);
+        for (int e = 0; e < 4; ++e) {  // quad 8t + 4h + e of the wave's 32: rows / columns relative to the wave's first quad
+          const int qi = 8 * t + 4 * h + e;
+          const int xa = xq0 + qi;                                // < owq + 32
+          const int dr = (int)(((float)xa + 0.5f) * inv_owq);     // xa / owq, exact for these small values
+          const int xq = xa - dr * owq;
+          co[e] = dr * a.ow + 4 * (xq - xq0);
+          room[e] = (int)Qw + qi > (int)Qe ? 0 : (a.ow - 4 * xq < 4 ? a.ow - 4 * xq : 4);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {

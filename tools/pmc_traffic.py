@@ -27,7 +27,7 @@ def family(name):
     if "depthwise" in name:
         return "depthwise3x3"
     if "conv3x3s2" in name:
-        return "conv3x3s2_first"
+        return "stem_conv"
     if "gemm_i8" in name:
         return "pointwise1x1"
     if "calib_f32_to_i8" in name:
@@ -56,6 +56,13 @@ def main():
                   "fetch_bytes_per_launch_raw": d["fetch_kib"] * 1024 / n,
                   "fetch_bytes_per_launch_x2": 2 * d["fetch_kib"] * 1024 / n,
                   "write_bytes_per_launch": d["write_kib"] * 1024 / n}
+    try:
+        import os
+        import subprocess
+        res["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__)),
+                                                stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:  # noqa: BLE001 - no git on the GPU box
+        res["commit"] = "unknown"
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

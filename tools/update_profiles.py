@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = os.path.join(ROOT, "gpurun_out", "evidence")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def cp(src, dst):
@@ -28,6 +28,10 @@ cp("layer_table.txt", "layer_table.txt")
 cp("bench.json", "bench.json")
 cp("bench_inflight1.json", "bench_inflight1.json")
 cp("gemm_timeline_pw8.txt", "gemm_timeline_pw8.txt")
+for f in ("bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.json", "layer_table_c4.txt", "layer_table_c5.txt",
+          "opbench_b256.txt", "opbench_fused.txt", "fused_timeline_dw8.txt", "gemm_tr_timeline_pw8.txt", "c2bench.txt"):
+    if os.path.exists(os.path.join(E, f)):
+        cp(f, f)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = glob.glob(os.path.join(E, kind, "*_counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -48,7 +52,8 @@ def g(f):
     return json.loads(open(os.path.join(E, f)).read().strip().splitlines()[-1])
 
 
-for f in ("bench.json", "bench_inflight1.json", "bench_inflight2.json", "bench_inflight4.json", "bench_streams2.json"):
+for f in ("bench.json", "bench_inflight1.json", "bench_inflight2.json", "bench_inflight4.json", "bench_c4.json", "bench_c5.json",
+          "bench_c2.json", "bench_force_dist.json"):
     d = g(f)
     print("%-24s %9.1f img/s  %.4f ms/step  roofline.frac %.4f" % (f, d["value"], d["ms_per_step"], d["roofline"]["frac"]))
 print(open(os.path.join(P, "%s_final_opbench.txt" % tag)).read().splitlines()[-1])
