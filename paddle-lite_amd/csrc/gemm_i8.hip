@@ -846,6 +846,12 @@ __global__ __launch_bounds__(256) void im2col_i8_kernel(Im2colArgs a) {
   const int ih0 = oy * a.sh - a.pt + kr * a.dh, iw0 = ox * a.sw - a.pl + kq * a.dw;
   if (a.sw == 1 && n + 3 < a.N && ox + 3 < a.ow && ih0 >= 0 && ih0 < a.h && iw0 >= 0 && iw0 + 3 < a.w) {
     __builtin_memcpy(&out, xp + (size_t)ih0 * a.w + iw0, 4);
+  } else if (a.sw == 2 && n + 3 < a.N && ox + 3 < a.ow && ih0 >= 0 && ih0 < a.h && iw0 >= 0 && iw0 + 7 < a.w) {
+    // stride 2 (ResNet50's 1x1 stride-2 shortcuts): columns iw0, +2, +4, +6 of one row: one unaligned 8-byte fetch,
+    // every other byte kept (the byte-by-byte walk below ran the three shortcut copies at ~1 TB/s)
+    uint32_t d[2];
+    __builtin_memcpy(d, xp + (size_t)ih0 * a.w + iw0, 8);
+    out = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u);
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -85,6 +85,31 @@ __device__ __forceinline__ v4i tr_requant_chunk(const v16i& acc, float s2, float
   return v;
 }
 
+// calib-only tail of an fp32-output conv (conv2d[fp32_out] -> calib with the fp32 value unused): the int8 value is
+// round_sat(inv2 * act(fma(acc, s, b))): the fp32 result is rounded first, then scaled and rounded again, exactly as the two
+// instructions do (type_trans.cc:45,183-184).  Same lane / register layout as tr_stage_i8.
+__device__ __forceinline__ void tr_stage_i8_calib(const v16i (&acc)[4][2], const float (&sc)[2], const float (&bi)[2], int act,
+                                                  float alpha, float inv2, uint8_t* stg, int c, int h) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint32_t dw[4];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        int qv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qv[e] = round_sat_i8(inv2 * epilogue_f32(acc[t][u][4 * gq + e], sc[u], bi[u], act, alpha));
+        dw[gq] = pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+      }
+      auto s02 = __builtin_amdgcn_permlane32_swap(dw[0], dw[2], false, false);
+      auto s13 = __builtin_amdgcn_permlane32_swap(dw[1], dw[3], false, false);
+      const v4i v = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+      *reinterpret_cast<v4i*>(stg + (32 * u + c) * 144 + (2 * t + h) * 16) = v;
+    }
+  }
+}
+
 template <int ACT>
 __device__ __forceinline__ void tr_stage_i8(const v16i (&acc)[4][2], const float (&sc)[2], const float (&bi)[2], float alpha,
                                             uint8_t* stg, int c, int h) {

@@ -295,11 +295,15 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
     __builtin_amdgcn_s_barrier();  // every wave has finished reading the ring: it becomes staging space
     PLHIP_TR_STAMP(TR_STAMP_SLOTS - 6);
     uint8_t* stg = ring + wave * (64 * 144);
-    switch (g.act) {  // wave-uniform: straight-line requantisation per activation
-      case ACT_RELU: tr_stage_i8<ACT_RELU>(acc, sc, bi, g.alpha, stg, c, h); break;
-      case ACT_RELU6: tr_stage_i8<ACT_RELU6>(acc, sc, bi, g.alpha, stg, c, h); break;
-      case ACT_LEAKY: tr_stage_i8<ACT_LEAKY>(acc, sc, bi, g.alpha, stg, c, h); break;
-      default: tr_stage_i8<ACT_NONE>(acc, sc, bi, g.alpha, stg, c, h); break;
+    if (g.y2) {  // kernel-uniform: calib-only tail of an fp32-output conv (launch_gemm_tr): the int8 tensor is g.y2
+      tr_stage_i8_calib(acc, sc, bi, g.act, g.alpha, g.inv_scale2, stg, c, h);
+    } else {
+      switch (g.act) {  // wave-uniform: straight-line requantisation per activation
+        case ACT_RELU: tr_stage_i8<ACT_RELU>(acc, sc, bi, g.alpha, stg, c, h); break;
+        case ACT_RELU6: tr_stage_i8<ACT_RELU6>(acc, sc, bi, g.alpha, stg, c, h); break;
+        case ACT_LEAKY: tr_stage_i8<ACT_LEAKY>(acc, sc, bi, g.alpha, stg, c, h); break;
+        default: tr_stage_i8<ACT_NONE>(acc, sc, bi, g.alpha, stg, c, h); break;
+      }
     }
     PLHIP_TR_STAMP(TR_STAMP_SLOTS - 5);  // requantised + staged
     // this lane's 16-column chunk (the same for all 8 store rounds) and its first row
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
       b = bi_;
     }
     const int m0 = mb * BM + wm * 64 + (lane >> 3);
-    int8_t* yp = reinterpret_cast<int8_t*>(g.y) + (size_t)b * g.y_bstride + (size_t)m0 * (uint32_t)g.HWY + hw;
+    int8_t* yp = (g.y2 ? g.y2 : reinterpret_cast<int8_t*>(g.y)) + (size_t)b * g.y_bstride + (size_t)m0 * (uint32_t)g.HWY + hw;
     const uint8_t* rp = stg + (lane >> 3) * 144 + (lane & 7) * 16;
     const bool fast = skip == 0 && room >= 16;
 #pragma unroll
@@ -484,6 +488,9 @@ bool launch_gemm_tr(const GemmArgs& g_in, int out, hipStream_t s) {
   // rows shorter than 16 bytes: only on the padded copy of the implicit route (a 16-byte piece may run past the row)
   if (!gemm_tr_enabled() || g.KS < 4 || (g.HWX < 16 && g.im_kw == 0)) return false;
   if ((long)g.NB * ((g.HWX + 15) & ~15) >= ((long)1 << 31) - 1024) return false;
+  // fp32-output conv whose fp32 value nobody reads and whose only tail is the calib: the staged int8 epilogue (16-byte
+  // row stores) instead of the row-per-lane 32-bit one (ResNet50's stem behind the int8 max pool: 0.54 -> see DESIGN 4)
+  if (out == OUT_F32 && !g.y && g.y2 && !g.res) out = OUT_I8;
 #define PLHIP_TR_OUT(WN_, WM_)                                          \
   do {                                                                  \
     if (out == OUT_I32) launch_tr_cfg<WN_, WM_, OUT_I32>(g, s);         \

@@ -42,9 +42,13 @@ def test_descriptor_helpers(pkg):
     # C2 runs as implicit GEMM: the workspace is the zero-padded input copy (58 x 58 planes + slack), not the im2col buffer
     assert lib.plhip_conv_workspace_bytes(ctypes.byref(d)) == 32 * 64 * 58 * 58 + 64
     assert lib.plhip_conv_impl_name(ctypes.byref(d)) == b"conv_implicit_gemm_int8_mfma32x32x32"
-    s2 = capi.conv_desc(32, 64, 56, 56, 128, 3, 3, (1, 1, 1, 1), (2, 2), (1, 1), 1)  # stride 2 stays on im2col + GEMM
-    assert lib.plhip_conv_workspace_bytes(ctypes.byref(s2)) == 32 * 576 * 784
-    assert lib.plhip_conv_impl_name(ctypes.byref(s2)) == b"conv_im2col_gemm_int8_mfma32x32x32"
+    # stride 2: implicit GEMM on the PHASE-SPLIT padded copy: 4 planes of ceil(58/2) x roundup(ceil(58/2), 4) per channel
+    s2 = capi.conv_desc(32, 64, 56, 56, 128, 3, 3, (1, 1, 1, 1), (2, 2), (1, 1), 1)
+    assert lib.plhip_conv_workspace_bytes(ctypes.byref(s2)) == 32 * 64 * 4 * 29 * 32 + 64
+    assert lib.plhip_conv_impl_name(ctypes.byref(s2)) == b"conv_implicit_gemm_int8_mfma32x32x32"
+    dil = capi.conv_desc(32, 64, 56, 56, 128, 3, 3, (2, 2, 2, 2), (1, 1), (2, 2), 1)  # dilation stays on im2col + GEMM
+    assert lib.plhip_conv_workspace_bytes(ctypes.byref(dil)) == 32 * 576 * 3136
+    assert lib.plhip_conv_impl_name(ctypes.byref(dil)) == b"conv_im2col_gemm_int8_mfma32x32x32"
     p = capi.conv_desc(128, 512, 14, 14, 512, 1, 1)
     assert lib.plhip_conv_workspace_bytes(ctypes.byref(p)) == 0
     assert lib.plhip_conv_impl_name(ctypes.byref(p)) == b"conv1x1s1_gemm_int8_mfma32x32x32"
