@@ -42,11 +42,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
   const size_t ylane = (size_t)b * g.y_bstride + hw + (size_t)(4 * h) * (uint32_t)g.HWY;
   const float hi2 = ACT == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
   const float lo2 = (ACT == ACT_RELU || ACT == ACT_RELU6) ? 0.f : -254.f;
+  // Fused residual operand: the 4 rows of group (a, gq) are fetched RD GROUPS AHEAD of their use.  Fetched where they are
+  // used, every group's loads sit behind the previous group's stores in the in-order memory queue (the compiler may not
+  // move a load above a store it cannot prove distinct) and the epilogue becomes one memory round trip per group:
+  // ResNet50's residual convs ran at ~4 TB/s.
+  constexpr int RD = 2;  // groups in flight ahead of the one being stored
+  float rbuf[RD + 1][4][4];
+  auto fetch_res = [&](int a, int gq, float (&r)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[e][i] = 0.f;
+      const int m = (mt * MA + a) * 32 + 8 * gq + 4 * h + e;
+      if (!MFULL && m >= g.M) continue;
+      const float* rp = g.res + ylane + (size_t)((uint32_t)((mt * MA + a) * 32 + 8 * gq + e) * (uint32_t)g.HWY);
+      if (VEC_STORE) {
+        const v4f rv = *reinterpret_cast<const v4f*>(rp);
+        r[e][0] = rv[0]; r[e][1] = rv[1]; r[e][2] = rv[2]; r[e][3] = rv[3];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i >= skip && i < hwy_room) r[e][i] = rp[i];
+      }
+    }
+  };
+  const bool has_res = OUT == OUT_F32 && g.res != nullptr;  // kernel-uniform
+  if (has_res) {
+#pragma unroll
+    for (int p = 0; p < RD && p < MA * 4; ++p) fetch_res(p >> 2, p & 3, rbuf[p]);
+  }
 #pragma unroll
   for (int a = 0; a < MA; ++a) {
     const int mbase = (mt * MA + a) * 32;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
+      const int gi = a * 4 + gq;
+      if (has_res && gi + RD < MA * 4) fetch_res((gi + RD) >> 2, (gi + RD) & 3, rbuf[(gi + RD) % (RD + 1)]);
       const int m0 = mbase + 8 * gq + 4 * h;
       if (!MFULL && m0 >= g.M) continue;
       const int mu0 = mbase + 8 * gq;  // uniform part of the row index
@@ -88,20 +119,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
             if (ACT == ACT_RELU6) f[i] = fminf(fmaxf(f[i], 0.f), g.alpha);
             if (ACT == ACT_LEAKY) f[i] = f[i] > 0.f ? f[i] : g.alpha * f[i];
           }
-          if (g.res) {  // fused residual add (+ relu): kernel-uniform
-            const float* rp = g.res + yoff;
-            float r[4] = {0.f, 0.f, 0.f, 0.f};
-            if (VEC_STORE) {
-              const v4f rv = *reinterpret_cast<const v4f*>(rp);
-              r[0] = rv[0]; r[1] = rv[1]; r[2] = rv[2]; r[3] = rv[3];
-            } else {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (i >= skip && i < hwy_room) r[i] = rp[i];
-            }
+          if (g.res) {  // fused residual add (+ relu): kernel-uniform; operand prefetched above
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              f[i] = f[i] + r[i];
+              f[i] = f[i] + rbuf[gi % (RD + 1)][e][i];
               if (g.res_relu) f[i] = f[i] > 0.f ? f[i] : 0.f;
             }
           }
