@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
   typedef integral_constant<bool, true> T_;
   typedef integral_constant<bool, false> F_;
   typedef integral_constant<int, D - 2> Y_;
-  static_assert(D == 4, "the tail below is written for 4 K-steps in flight (even: the register sets alternate)");
+  static_assert(D == 3 || D == 4, "the tail below is written out for 3 or 4 K-steps in flight");
   {
     // steps 0 .. S-1 (S = KS - D) issue and read ahead; then ks = KS-D+T, T = 0 .. D-2: (D-2-T, -, next); KS-1: (0, -, -).
     // The sets alternate with ks; an odd S starts in set 1 so that the tail always starts in set 0.
@@ -278,10 +278,16 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void gemm_i8_tr_kernel(GemmArgs g)
       step(ks, fs[0], fs[1], Y_{}, T_{}, T_{});
       step(ks + 1, fs[1], fs[0], Y_{}, T_{}, T_{});
     }
-    step(ks, fs[0], fs[1], integral_constant<int, 2>{}, F_{}, T_{});
-    step(ks + 1, fs[1], fs[0], integral_constant<int, 1>{}, F_{}, T_{});
-    step(ks + 2, fs[0], fs[1], integral_constant<int, 0>{}, F_{}, T_{});
-    step(ks + 3, fs[1], fs[0], integral_constant<int, 0>{}, F_{}, F_{});
+    if (D == 4) {
+      step(ks, fs[0], fs[1], integral_constant<int, 2>{}, F_{}, T_{});
+      step(ks + 1, fs[1], fs[0], integral_constant<int, 1>{}, F_{}, T_{});
+      step(ks + 2, fs[0], fs[1], integral_constant<int, 0>{}, F_{}, T_{});
+      step(ks + 3, fs[1], fs[0], integral_constant<int, 0>{}, F_{}, F_{});
+    } else {
+      step(ks, fs[0], fs[1], integral_constant<int, 1>{}, F_{}, T_{});
+      step(ks + 1, fs[1], fs[0], integral_constant<int, 0>{}, F_{}, T_{});
+      step(ks + 2, fs[0], fs[1], integral_constant<int, 0>{}, F_{}, F_{});
+    }
   }
 
   PLHIP_TR_STAMP(TR_STAMP_SLOTS - 4);
@@ -451,7 +457,9 @@ int gemm_tr_enabled() {  // PLHIP_GEMM_TR=0: first-generation kernels only (A/B 
 
 template <int WN, int WM, int OUT, bool IM>
 static void launch_tr_cfg2(GemmArgs g, hipStream_t s) {
-  constexpr int D = 4;
+  // 4-wave blocks (M <= 64): 3 K-steps in flight = 4 ring slots = 72 KiB, so that TWO blocks share a CU (with one, its
+  // four waves read LDS together and multiply together: 11 B/clk of ingest; two blocks de-phase each other)
+  constexpr int D = WN * WM == 4 ? 3 : 4;
   constexpr int BN = WN * 128, BM = WM * 64;
   const int HWP = (g.HWX + 15) & ~15;
   g.NT = (int)(((long)g.NB * HWP + BN - 1) / BN);  // blocks along N
@@ -499,11 +507,14 @@ bool launch_gemm_tr(const GemmArgs& g_in, int out, hipStream_t s) {
   } while (0)
   static int cfg_env = -1;
   if (cfg_env < 0) {
+    // default 3: 4-wave blocks (128 x 256 / 256 x 128 tiles), two per CU, for every M (ResNet50's 3x3 layers: 5-8 % faster
+    // than one 8-wave block per CU, whose waves read LDS together and multiply together); 0 = the 8-wave tiles
     const char* e = getenv("PLHIP_TR_CFG");
-    cfg_env = e ? atoi(e) : 0;
+    cfg_env = e ? atoi(e) : 3;
   }
-  if (g.M > 128 && cfg_env == 1) PLHIP_TR_OUT(1, 4);
+  if (g.M > 128 && (cfg_env & 1)) PLHIP_TR_OUT(1, 4);
   else if (g.M > 128) PLHIP_TR_OUT(2, 4);
+  else if (g.M > 64 && (cfg_env & 2)) PLHIP_TR_OUT(2, 2);
   else if (g.M > 64) PLHIP_TR_OUT(4, 2);
   else PLHIP_TR_OUT(4, 1);
 #undef PLHIP_TR_OUT

@@ -26,14 +26,22 @@ def main():
     ap.add_argument("layer", nargs="?", default="pw8")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--tr", action="store_true", help="the transposed-read ring kernel (gemm_tr_i8.hip): 8 waves per block")
+    ap.add_argument("--conv", default=None, help="cin,cout,hw,k,stride: a dense conv of that shape instead of a MobileNetV1 layer (implies --tr)")
     args = ap.parse_args()
+    if args.conv:
+        args.tr = True
     WPB = 8 if args.tr else 4
     assert int(os.environ.get("PLHIP_GEMM_DEBUG", "0")) & 32, "run with PLHIP_GEMM_DEBUG=32 (or 33, 34 ...)"
     rng = np.random.default_rng(0)
     B = args.batch
     with capi.Context(0) as ctx:
         L = ctx.L
-        for (name, op, cin, cout, k, s, p, g, hin) in wl.mobilenet_v1_layers():
+        layers = wl.mobilenet_v1_layers()
+        if args.conv:
+            cin, cout, hin, k, s = [int(v) for v in args.conv.split(",")]
+            layers = [("conv", "conv2d", cin, cout, k, s, k // 2, 1, hin)]
+            args.layer = "conv"
+        for (name, op, cin, cout, k, s, p, g, hin) in layers:
             if name != args.layer:
                 continue
             ho = (hin + 2 * p - k) // s + 1
@@ -46,11 +54,13 @@ def main():
             dy = ctx.malloc(B * cout * ho * ho)
             dwp = ctx.malloc(L.plhip_conv_packed_weight_bytes(C.byref(d)))
             ctx.check(L.plhip_pack_conv_weights(ctx.h, C.byref(d), dw, dwp), "pack")
+            wsb = L.plhip_conv_workspace_bytes(C.byref(d))
+            dws = ctx.malloc(wsb) if wsb else None
             for _ in range(20):  # warm clocks and caches; the stamps of the last launch stay
-                ctx.check(L.plhip_conv2d_int8(ctx.h, C.byref(d), dx, dwp, ds, db, dy, capi.OUT_I8, None, 0), "conv")
+                ctx.check(L.plhip_conv2d_int8(ctx.h, C.byref(d), dx, dwp, ds, db, dy, capi.OUT_I8, dws, wsb), "conv")
             ctx.sync()
             hwp = (ho * ho + 15) // 16 * 16
-            nblk = min(1024, ((cout + 255) // 256) * ((B * hwp + 127) // 128 + 7) // 8 * 8)
+            nblk = 1024 if args.conv else min(1024, ((cout + 255) // 256) * ((B * hwp + 127) // 128 + 7) // 8 * 8)
             buf = np.zeros(1024 * WPB * SLOTS, np.uint64)
             rd = L.plhip_debug_read_tr_stamps if args.tr else L.plhip_debug_read_stamps
             rd.argtypes = [C.c_void_p, C.c_size_t]
@@ -60,7 +70,7 @@ def main():
             live = st[:, :, 1] != 0
             st = st[live[:, 0]]
             print("blocks with stamps:", st.shape[0], "of", nblk)
-            ks = (cin + 31) // 32
+            ks = (cin * k * k // g + 31) // 32
             rt0 = st[:, 0, 0]
             rt1 = st[:, :, SLOTS - 1].max(axis=1)
             print("realtime (100 MHz ticks): first start %d, last start +%d, last end +%d  => kernel span %.2f us" % (
