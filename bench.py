@@ -138,9 +138,13 @@ class HipEngine:
         self.pred.set_input("image", image)
         self.pred.run(skip_io_copy=False)  # uploads the feed; PrepareForRun (weight pack, scale fold) everywhere
         self.pred.sync()
+        self.use_graph = os.environ.get("PLHIP_BENCH_GRAPH", "0") == "1"
 
     def run(self):
-        self.pred.run(skip_io_copy=True)
+        if self.use_graph:
+            self.pred.run_graph()  # the step as ONE recorded launch graph (hipGraph): recorded at the first call
+        else:
+            self.pred.run(skip_io_copy=True)
 
     def stage(self, dst, nbytes):
         self.pred.copy_var_to_device(self.out_var, dst.data_ptr(), nbytes)

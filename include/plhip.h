@@ -73,6 +73,17 @@ plhip_status plhip_memcpy_d2h(plhip_ctx* ctx, void* dst_host, const void* src_de
 plhip_status plhip_memcpy_d2d(plhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 plhip_status plhip_memset(plhip_ctx* ctx, void* dst_dev, int value, size_t bytes);
 plhip_status plhip_stream_sync(plhip_ctx* ctx);
+/* ---- launch graphs (no counterpart in the reference: its CUDA backend launches kernel by kernel) ----
+ * Every compute entry point is asynchronous, allocation-free and argument-static, so a whole program step can be recorded
+ * once and replayed: plhip_graph_begin puts the context's stream into capture (hipStreamBeginCapture, thread-local mode);
+ * the caller issues its launches as usual; plhip_graph_end ends the capture and instantiates an executable graph;
+ * plhip_graph_launch replays it on the context's stream (one submission instead of ~30, no per-kernel dispatch gap).
+ * Pointers baked into the recorded launches must stay valid; anything that synchronises or allocates is illegal between
+ * begin and end (the first, un-captured run of a program does the one-time work: weight packing, workspace, attributes). */
+plhip_status plhip_graph_begin(plhip_ctx* ctx);
+plhip_status plhip_graph_end(plhip_ctx* ctx, void** graph_exec);
+plhip_status plhip_graph_launch(plhip_ctx* ctx, void* graph_exec);
+plhip_status plhip_graph_destroy(plhip_ctx* ctx, void* graph_exec);
 /* hipEvent timing on the context's stream (DeviceTimer<kCUDA> analogue, lite/core/profile/timer.h:127-158). */
 plhip_status plhip_event_create(plhip_ctx* ctx, void** event);
 plhip_status plhip_event_record(plhip_ctx* ctx, void* event);

@@ -22,7 +22,7 @@ EXPORTS = [
     "plhip_memcpy_d2h", "plhip_memcpy_d2d", "plhip_memset", "plhip_stream_sync", "plhip_event_create",
     "plhip_event_record", "plhip_event_elapsed_ms", "plhip_event_destroy",
     "plhip_conv_packed_weight_bytes", "plhip_pack_conv_weights", "plhip_conv_workspace_bytes",
-    "plhip_conv2d_int8", "plhip_conv2d_int8_fused", "plhip_conv_impl_name", "plhip_depthwise_conv_int8", "plhip_dwpw_fused_int8", "plhip_dwpw_fused_supported",
+    "plhip_conv2d_int8", "plhip_conv2d_int8_fused", "plhip_conv_impl_name", "plhip_depthwise_conv_int8", "plhip_dwpw_fused_int8", "plhip_dwpw_fused_supported", "plhip_graph_begin", "plhip_graph_end", "plhip_graph_launch", "plhip_graph_destroy",
     "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
     "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
     "plhip_pool2d_f32", "plhip_pool2d_max_i8", "plhip_elementwise_add_f32", "plhip_selftest",

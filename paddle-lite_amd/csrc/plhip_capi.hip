@@ -227,6 +227,31 @@ plhip_status plhip_stream_sync(plhip_ctx* ctx) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return PLHIP_OK;
 }
+plhip_status plhip_graph_begin(plhip_ctx* ctx) {
+  if (!ctx) return fail(ctx, PLHIP_ERR_INVALID, "null ctx");
+  HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  return PLHIP_OK;
+}
+plhip_status plhip_graph_end(plhip_ctx* ctx, void** graph_exec) {
+  if (!ctx || !graph_exec) return fail(ctx, PLHIP_ERR_INVALID, "null argument");
+  hipGraph_t g = nullptr;
+  HIPCHK(ctx, hipStreamEndCapture(ctx->stream, &g));
+  hipGraphExec_t e = nullptr;
+  const hipError_t st = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (st != hipSuccess) return fail(ctx, PLHIP_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(st));
+  *graph_exec = (void*)e;
+  return PLHIP_OK;
+}
+plhip_status plhip_graph_launch(plhip_ctx* ctx, void* graph_exec) {
+  if (!ctx || !graph_exec) return fail(ctx, PLHIP_ERR_INVALID, "null argument");
+  HIPCHK(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+  return PLHIP_OK;
+}
+plhip_status plhip_graph_destroy(plhip_ctx* ctx, void* graph_exec) {
+  if (graph_exec) HIPCHK(ctx, hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return PLHIP_OK;
+}
 plhip_status plhip_event_create(plhip_ctx* ctx, void** event) {
   if (!ctx || !event) return fail(ctx, PLHIP_ERR_INVALID, "null argument");
   hipEvent_t e;

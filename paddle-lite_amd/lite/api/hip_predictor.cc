@@ -1,6 +1,8 @@
 // hip_predictor.cc — see hip_predictor.h.
 #include "lite/api/hip_predictor.h"
 
+#include "plhip.h"
+
 #include <cstring>
 
 namespace paddle {
@@ -192,6 +194,21 @@ std::vector<std::string> HipPredictor::KernelNames() {
   for (auto& i : program_.instructions())
     r.push_back(i.kernel()->name() + "/" + i.kernel()->alias() + " -> " + i.kernel()->kernel_func_name());
   return r;
+}
+
+void HipPredictor::RunGraph() {
+  TargetWrapperHip::SetDevice(device_);
+  plhip_ctx* ctx = state()->ctx();
+  if (!graph_exec_) {
+    HIP_CALL(ctx, plhip_graph_begin(ctx));
+    program_.Run(/*skip_io_copy=*/true);  // InferShape() + Launch() per instruction, recorded instead of executed
+    HIP_CALL(ctx, plhip_graph_end(ctx, &graph_exec_));
+  }
+  HIP_CALL(ctx, plhip_graph_launch(ctx, graph_exec_));
+}
+
+HipPredictor::~HipPredictor() {
+  if (graph_exec_ && state_) (void)plhip_graph_destroy(state_->ctx(), graph_exec_);
 }
 
 }  // namespace lite

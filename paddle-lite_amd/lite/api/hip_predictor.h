@@ -63,6 +63,11 @@ class HipPredictor {
     TargetWrapperHip::SetDevice(device_);
     program_.Run(skip_io_copy);
   }
+  // Replays the device part of the program (everything but the io_copy instructions) as ONE launch graph: recorded on
+  // the first call (the program must have run once before: PrepareForRun, workspace), replayed afterwards.  Feeds and
+  // fetches keep their device addresses, so new input is a plain copy into the feed's device tensor before the call.
+  void RunGraph();
+  ~HipPredictor();
   // The predictor's execution state (device stream + workspace): the creating thread's default state at the first
   // instruction (after pllite_adopt_stream: the adopted stream), kept for life — Run() from any thread uses it.
   const std::shared_ptr<HipExecState>& state();
@@ -75,6 +80,7 @@ class HipPredictor {
   Tensor* NewParam(const void* host, size_t bytes, const std::vector<int64_t>& dims, PrecisionType prec);
   int device_;
   std::shared_ptr<HipExecState> state_;
+  void* graph_exec_{nullptr};  // plhip launch graph of the program (RunGraph)
   std::map<std::string, std::unique_ptr<Tensor>> vars_;
   std::vector<std::unique_ptr<Tensor>> params_;
   RuntimeProgram program_;

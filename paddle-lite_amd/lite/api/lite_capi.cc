@@ -251,6 +251,9 @@ int pllite_set_input(pllite_predictor* p, const char* name, const void* host, in
 int pllite_run(pllite_predictor* p, int skip_io_copy) {
   return guarded([&] { p->pred.Run(skip_io_copy != 0); });
 }
+int pllite_run_graph(pllite_predictor* p) {
+  return guarded([&] { p->pred.RunGraph(); });
+}
 int pllite_num_instructions(pllite_predictor* p) { return static_cast<int>(p->pred.program().instructions().size()); }
 int pllite_run_instruction(pllite_predictor* p, int index) {
   return guarded([&] {

@@ -74,6 +74,8 @@ int pllite_graph_op_params(pllite_predictor* p, int index, char* type, int type_
 
 int pllite_set_input(pllite_predictor* p, const char* name, const void* host, int64_t bytes);
 int pllite_run(pllite_predictor* p, int skip_io_copy);
+// the device part of the program as one recorded launch graph (first call records; needs one earlier pllite_run)
+int pllite_run_graph(pllite_predictor* p);
 int pllite_sync(pllite_predictor* p);
 /* Per-instruction stepping (bench.py brackets single launches with HIP events for the roofline object). */
 int pllite_num_instructions(pllite_predictor* p);

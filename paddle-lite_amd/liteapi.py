@@ -61,6 +61,7 @@ def load():
                                          C.POINTER(f32), C.POINTER(i32), C.POINTER(f32)]
     L.pllite_set_input.argtypes = [vp, cs, vp, i64]
     L.pllite_run.argtypes = [vp, i32]
+    L.pllite_run_graph.argtypes = [vp]
     L.pllite_sync.argtypes = [vp]
     L.pllite_num_instructions.argtypes = [vp]
     L.pllite_run_instruction.argtypes = [vp, i32]
@@ -233,6 +234,10 @@ class Predictor:
 
     def run(self, skip_io_copy=False):
         self._ck(self.L.pllite_run(self.h, int(skip_io_copy)))
+
+    def run_graph(self):
+        """Device part of the program as ONE recorded launch graph (records on the first call, after a plain run())."""
+        self._ck(self.L.pllite_run_graph(self.h))
 
     def sync(self):
         self._ck(self.L.pllite_sync(self.h))

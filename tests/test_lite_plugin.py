@@ -297,3 +297,32 @@ def test_device_timer_and_kernel_func_name(lite):
         assert p.time_instruction(0, reps=1)[2] == "io_copy_host_to_hip"
     finally:
         p.close()
+
+
+@pytest.mark.gpu
+def test_launch_graph_replays_the_program_bit_for_bit(lite, wl, plref):
+    """HipPredictor::RunGraph: the device part of the program recorded once as a launch graph (plhip_graph_*) and replayed
+    must produce exactly the bytes of the instruction-by-instruction run — also after the feed changed (the graph holds
+    device addresses, not data)."""
+    net = wl.mobilenet_v1_net(seed=11)
+    rng = np.random.default_rng(12)
+    p = lite.Predictor(0)
+    try:
+        wl.emit_graph(p, net, 2)
+        p.graph_lower()
+        img = rng.uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+        p.set_input(net["input"], img)
+        p.run()
+        want = p.get_var(net["output"], np.float32).copy()
+        p.run_graph()   # records, then launches
+        p.run_graph()   # replays
+        assert np.array_equal(p.get_var(net["output"], np.float32), want)
+        img2 = rng.uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+        p.set_input(net["input"], img2)
+        p.run()         # uploads the new feed, runs kernel by kernel
+        want2 = p.get_var(net["output"], np.float32).copy()
+        assert not np.array_equal(want, want2)
+        p.run_graph()
+        assert np.array_equal(p.get_var(net["output"], np.float32), want2)
+    finally:
+        p.close()
