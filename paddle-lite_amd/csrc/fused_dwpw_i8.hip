@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw_kernel(FusedArgs a) {
   int mb, nb;
   tr_xcd_tile_map(blockIdx.x, g.MT, g.NT, mb, nb);
   if (nb >= g.NT) return;  // block-uniform (grid padded to 8 N blocks)
-  const int dbg = g.dbg;   // PLHIP_FUSED_DEBUG (timing experiments only): 2 = no MFMAs, 4 = no depthwise arithmetic, 32 = stamps
+  const int dbg = g.dbg;   // PLHIP_FUSED_DEBUG (timing experiments only): 4 = no depthwise arithmetic, 32 = stamps
   const bool diag = (dbg & 32) != 0;
   unsigned long long* lstamp = lstamp_all + wave * FZ_STAMP_SLOTS;
   if (diag && lane == 0) {
@@ -448,17 +448,13 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw_kernel(FusedArgs a) {
     issue_raw(ks + L + 2);
     issue_w(ks + L + 1, wset[(CS + L + 1) % (L + 2)]);
     auto multiply = [&]() __attribute__((always_inline)) {
-      if (!(dbg & 2)) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const v4i av = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
-            acc[t][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wset[CS][u], acc[t][u], 0, 0, 0);
-          }
-      } else {
-        acc[0][0][0] += lo[0][0] ^ lo[1][1] ^ hi[2][0] ^ hi[3][1] ^ wset[CS][0][0] ^ wset[CS][1][3];
-      }
+        for (int t = 0; t < 4; ++t) {
+          const v4i av = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+          acc[t][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wset[CS][u], acc[t][u], 0, 0, 0);
+        }
     };
     // MFMAs FIRST: a wave sits in its 8 MFMAs for ~256 cycles while the matrix pipe is busy; the other wave of the SIMD
     // queues behind it, so the two skew by one MFMA block and each one's depthwise VALU work then overlaps the other's
