@@ -48,6 +48,16 @@ constexpr int fz_maxpwd(int wn) { return wn >= 8 ? 8 : (wn >= 2 ? 4 : 2); }
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (clamped to 40: a smaller count only waits longer)
 __device__ __forceinline__ void fz_wait_vmcnt(int n) {
 #define FZ_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+  // the steady-state counts of the common shapes first (1 or 2 DMA instructions per wave and K-step): the general switch
+  // below is a 6-deep tree of scalar compares and taken branches, ~300 cycles per K-step in the timeline
+  if (n == 6) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    return;
+  }
+  if (n == 8) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    return;
+  }
   switch (n < 40 ? n : 40) {
     FZ_W(0) FZ_W(1) FZ_W(2) FZ_W(3) FZ_W(4) FZ_W(5) FZ_W(6) FZ_W(7) FZ_W(8) FZ_W(9) FZ_W(10) FZ_W(11) FZ_W(12) FZ_W(13)
     FZ_W(14) FZ_W(15) FZ_W(16) FZ_W(17) FZ_W(18) FZ_W(19) FZ_W(20) FZ_W(21) FZ_W(22) FZ_W(23) FZ_W(24) FZ_W(25) FZ_W(26)
@@ -116,7 +126,7 @@ __device__ __forceinline__ FzOut fz_quad_out(long Q, long NQ, int owq, int oh, i
 
 // ---- diagnostic timeline (PLHIP_FUSED_DEBUG & 32; never set in production): per-wave s_memtime stamps kept in LDS and
 // flushed at the end (plhip_debug_read_fz_stamps; tools/fused_timeline.py).  Slots: 0 realtime start, 1 entry, 2 dw
-// parameters visible, 3 first K-step produced, 4+ks top of K-step ks (ks < 20), 26 loop end, 27 staged, 28 stores issued,
+// parameters visible, 3 first K-step produced, 4+ks top of K-step ks (ks < 16), 20-24 sub-stamps of K-step 6 (& 64), 26 loop end, 27 staged, 28 stores issued,
 // 29 stores acknowledged, 31 realtime end
 constexpr int FZ_STAMP_SLOTS = 32;
 __device__ unsigned long long g_fz_stamps[1024 * 8 * FZ_STAMP_SLOTS];
@@ -429,14 +439,17 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw_kernel(FusedArgs a) {
   // K-step ks: weights(ks) live in wset[CS]; weights(ks + L + 1) are requested into wset[(CS + L + 1) % (L + 2)]
   auto step = [&](int ks, auto cs_c) __attribute__((always_inline)) {
     constexpr int CS = decltype(cs_c)::value;
-    if (ks < 20) PLHIP_FZ_STAMP(4 + ks);
+    if (ks < 16) PLHIP_FZ_STAMP(4 + ks);
+    const bool sub = diag && (dbg & 64) && ks == 6;  // sub-stamps of one steady-state K-step: slots 20 .. 24
     // everything this wave issued up to K-step ks - L - 1 has landed: raw(ks + 1) and weights(ks)
     fz_wait_vmcnt(L * step_ops);
     asm volatile("" : "+v"(wset[CS][0]), "+v"(wset[CS][1]));
     fix_edges(ks + 1);
     // my writes of activation K-step ks are done; after the barrier everyone's raw(ks + 1) pieces and activation
     // K-step ks are visible, and nobody reads raw(ks) / activation K-step ks - 1 any more
+    if (sub && lane == 0) lstamp[20] = __builtin_amdgcn_s_memtime();  // counted wait done
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (sub && lane == 0) lstamp[21] = __builtin_amdgcn_s_memtime();  // barrier passed
     uint8_t* cur = fsm + (ks & 1) * ACT_SLOT;
     uint8_t* nxt = fsm + ((ks + 1) & 1) * ACT_SLOT;
     v2i lo[4], hi[4];
@@ -459,8 +472,11 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw_kernel(FusedArgs a) {
     // MFMAs FIRST: a wave sits in its 8 MFMAs for ~256 cycles while the matrix pipe is busy; the other wave of the SIMD
     // queues behind it, so the two skew by one MFMA block and each one's depthwise VALU work then overlaps the other's
     // MFMAs (produce-first made both waves compete for the VALU and then both queue for the matrix pipe)
+    if (sub && lane == 0) lstamp[22] = __builtin_amdgcn_s_memtime();  // transposed reads + DMA + weight loads issued
     multiply();
+    if (sub && lane == 0) lstamp[23] = __builtin_amdgcn_s_memtime();  // MFMAs issued
     if (ks + 1 < KS) produce(ks + 1, nxt);
+    if (sub && lane == 0) lstamp[24] = __builtin_amdgcn_s_memtime();  // next K-step's activations written
   };
   static_assert(L + 2 == 4 && D == 4, "the loop below is unrolled for 4 weight sets / ring slots");
   for (int ks = 0; ks < KS; ks += 4) {
@@ -491,64 +507,15 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw_kernel(FusedArgs a) {
   if (OUT == OUT_I8) {
     __builtin_amdgcn_s_barrier();  // every wave has finished reading the activation slots: they become staging space
     uint8_t* stg = fsm + wave * (64 * 144);
-    if ((a.ow & 3) == 0) {  // kernel-uniform: every quad is whole, the compact image is the padded one
-      switch (g.act) {      // wave-uniform: straight-line requantisation per activation
-        case ACT_RELU: tr_stage_i8<ACT_RELU>(acc, sc, bi, g.alpha, stg, c, h); break;
-        case ACT_RELU6: tr_stage_i8<ACT_RELU6>(acc, sc, bi, g.alpha, stg, c, h); break;
-        case ACT_LEAKY: tr_stage_i8<ACT_LEAKY>(acc, sc, bi, g.alpha, stg, c, h); break;
-        default: tr_stage_i8<ACT_NONE>(acc, sc, bi, g.alpha, stg, c, h); break;
-      }
-    } else {
-      // OW % 4 != 0: the quad's dword goes to its COMPACT byte offset (flat pixel index relative to the wave's first
-      // pixel), only its valid bytes, as naturally aligned 16-bit (even OW) / 8-bit writes
-      const uint32_t stg_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stg;
-      const int xq0 = (int)Qw % owq;  // wave-uniform
-      const float inv_owq = 1.0f / (float)owq;
-      const float hi2 = g.act == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
-      const float lo2 = (g.act == ACT_RELU || g.act == ACT_RELU6) ? 0.f : -254.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        int co[4], room[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {  // quad 8t + 4h + e of the wave's 32: rows / columns relative to the wave's first quad
-          const int qi = 8 * t + 4 * h + e;
-          const int xa = xq0 + qi;                                // < owq + 32
-          const int dr = (int)(((float)xa + 0.5f) * inv_owq);     // xa / owq, exact for these small values
-          const int xq = xa - dr * owq;
-          co[e] = dr * a.ow + 4 * (xq - xq0);
-          room[e] = (int)Qw + qi > (int)Qe ? 0 : (a.ow - 4 * xq < 4 ? a.ow - 4 * xq : 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const float s2 = sc[u] + sc[u], b2 = bi[u] + bi[u];
-          v4i v;
-          switch (g.act) {
-            case ACT_RELU: v = tr_requant_chunk<ACT_RELU>(acc[t][u], s2, b2, g.alpha, lo2, hi2); break;
-            case ACT_RELU6: v = tr_requant_chunk<ACT_RELU6>(acc[t][u], s2, b2, g.alpha, lo2, hi2); break;
-            case ACT_LEAKY: v = tr_requant_chunk<ACT_LEAKY>(acc[t][u], s2, b2, g.alpha, lo2, hi2); break;
-            default: v = tr_requant_chunk<ACT_NONE>(acc[t][u], s2, b2, g.alpha, lo2, hi2); break;
-          }
-          const uint32_t rowa = stg_addr + (32 * u + c) * 144;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t ad = rowa + co[e];
-            const uint32_t d = (uint32_t)v[e];
-            if (!(a.ow & 1)) {  // kernel-uniform: even OW: every compact offset is even: 16-bit writes
-              if (room[e] >= 2) asm volatile("ds_write_b16 %0, %1" ::"v"(ad), "v"(d) : "memory");
-              if (room[e] == 4) asm volatile("ds_write_b16_d16_hi %0, %1 offset:2" ::"v"(ad), "v"(d) : "memory");
-            } else {
-              if (room[e] >= 1) asm volatile("ds_write_b8 %0, %1" ::"v"(ad), "v"(d) : "memory");
-              if (room[e] >= 2) asm volatile("ds_write_b8 %0, %1 offset:1" ::"v"(ad), "v"(d >> 8) : "memory");
-              if (room[e] >= 3) asm volatile("ds_write_b8_d16_hi %0, %1 offset:2" ::"v"(ad), "v"(d) : "memory");
-              if (room[e] == 4) asm volatile("ds_write_b8 %0, %1 offset:3" ::"v"(ad), "v"(d >> 24) : "memory");
-            }
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    switch (g.act) {  // wave-uniform: straight-line requantisation per activation; PADDED image: quad qi at byte 4 * qi
+      case ACT_RELU: tr_stage_i8<ACT_RELU>(acc, sc, bi, g.alpha, stg, c, h); break;
+      case ACT_RELU6: tr_stage_i8<ACT_RELU6>(acc, sc, bi, g.alpha, stg, c, h); break;
+      case ACT_LEAKY: tr_stage_i8<ACT_LEAKY>(acc, sc, bi, g.alpha, stg, c, h); break;
+      default: tr_stage_i8<ACT_NONE>(acc, sc, bi, g.alpha, stg, c, h); break;
     }
     PLHIP_FZ_STAMP(27);
-    // lane -> row lane>>3 of each 8-row round, compact bytes [16 j, 16 j + 16), j = lane & 7, of the wave's pixels
+    // lane -> row lane>>3 of each 8-row round, COMPACT bytes [16 j, 16 j + 16), j = lane & 7, of the wave's pixels (the
+    // padding columns of a row's last quad dropped)
     const int HW = g.HWY;
     const int P0 = fz_pixel((int)Qw, owq, a.ow);
     const int Pend = fz_pixel((int)(Qw + 32 < NQ ? Qw + 32 : NQ), owq, a.ow);  // fz_pixel(NQ) = n * HW
@@ -561,21 +528,58 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw_kernel(FusedArgs a) {
     const int m0 = mb * BM + wm * 64 + (lane >> 3);
     int8_t* y1 = reinterpret_cast<int8_t*>(g.y) + (size_t)b * g.y_bstride + (size_t)m0 * (uint32_t)HW + p;
     int8_t* y2 = reinterpret_cast<int8_t*>(g.y) + (size_t)(b + 1) * g.y_bstride + (size_t)m0 * (uint32_t)HW - cnt1;
-    const uint8_t* rp = stg + (lane >> 3) * 144 + (lane & 7) * 16;
-    if (cnt1 == 16) {
+    const uint8_t* rrow = stg + (lane >> 3) * 144;
+    // OW % 4 != 0: compact dword d of this lane = the last roomA - sA bytes of quad A followed by the first bytes of quad
+    // A + 1: two aligned LDS dwords, one shift, one v_alignbyte (OW % 4 == 1, where a dword can span three quads, is kept
+    // off this path by fused_dwpw_plan)
+    const bool packed = (a.ow & 3) != 0;  // kernel-uniform
+    int offA[4] = {0, 0, 0, 0}, shl[4] = {0, 0, 0, 0}, sel[4] = {0, 0, 0, 0};
+    if (packed) {
+      int gr = P / a.ow, x = P - gr * a.ow;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const v4i v = *reinterpret_cast<const v4i*>(rp + i * 8 * 144);
-        if (m0 + 8 * i < g.M) __builtin_memcpy(y1 + (size_t)(8 * i) * (uint32_t)HW, &v, 16);  // possibly unaligned: fine for global memory
-      }
-    } else if (nvalid > 0) {  // the tile's last bytes / a run crossing into the next image: byte stores (rare lanes)
-      for (int i = 0; i < 8 && m0 + 8 * i < g.M; ++i) {
-        const size_t ro = (size_t)(8 * i) * (uint32_t)HW;
-        for (int e = 0; e < nvalid; ++e) {
-          const int8_t bv = (int8_t)rp[i * 8 * 144 + e];
-          if (e < cnt1) y1[ro + e] = bv;
-          else y2[ro + e] = bv;
+      for (int d = 0; d < 4; ++d) {
+        const int Q = gr * owq + (x >> 2);
+        const int roomA = a.ow - (x & ~3) < 4 ? a.ow - (x & ~3) : 4;
+        int oa = 4 * (Q - (int)Qw);
+        offA[d] = oa < 0 ? 0 : (oa > 120 ? 120 : oa);  // lanes past the wave's pixels: any legal offset (nothing stored)
+        shl[d] = 8 * (4 - roomA);
+        sel[d] = 4 - roomA + (x & 3);
+        x += 4;
+        if (x >= a.ow) {
+          x -= a.ow;
+          ++gr;
         }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v4i v;
+      if (!packed) {
+        v = *reinterpret_cast<const v4i*>(rrow + i * 8 * 144 + (lane & 7) * 16);
+      } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const uint32_t qa = *reinterpret_cast<const uint32_t*>(rrow + i * 8 * 144 + offA[d]);
+          const uint32_t qb = *reinterpret_cast<const uint32_t*>(rrow + i * 8 * 144 + offA[d] + 4);
+          v[d] = (int)__builtin_amdgcn_alignbyte(qb, qa << shl[d], (uint32_t)sel[d]);
+        }
+      }
+      if (m0 + 8 * i >= g.M || nvalid == 0) continue;
+      const size_t ro = (size_t)(8 * i) * (uint32_t)HW;
+      if (cnt1 == 16) {
+        __builtin_memcpy(y1 + ro, &v, 16);  // possibly unaligned: fine for global memory
+      } else if (!(a.ow & 1)) {
+        // the tile's last bytes / a run crossing into the next image (rare lanes); even OW: everything is 2-byte aligned
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (2 * e < nvalid) {
+            const uint16_t hv = (uint16_t)((uint32_t)v[e >> 1] >> (16 * (e & 1)));
+            *reinterpret_cast<uint16_t*>((2 * e < cnt1 ? y1 : y2) + ro + 2 * e) = hv;
+          }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (e < nvalid) ((e < cnt1 ? y1 : y2))[ro + e] = (int8_t)((uint32_t)v[e >> 2] >> (8 * (e & 3)));
       }
     }
   } else {
@@ -669,6 +673,7 @@ bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int d
   const long total = (long)a->n * a->C * a->h * a->w;
   if (total >= ((long)1 << 31) - 64 || total < 16 || (long)a->oh * a->ow < 16) return false;
   if ((long)a->n * a->oh * ((a->ow + 3) / 4 * 4) >= ((long)1 << 31) - 4096) return false;  // quad / pixel indices stay 32-bit
+  if (out == OUT_I8 && (a->ow & 3) == 1) return false;  // int8 epilogue: a compact dword would span three quads (room 1)
   a->owq = (a->ow + 3) / 4;
   a->NQ = (long)a->n * a->oh * a->owq;
   const int M = a->pw.M;

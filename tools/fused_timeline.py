@@ -70,9 +70,16 @@ def main():
             ks = (cin + 31) // 32
             show("entry -> dw parameters visible", t[:, 2] - t[:, 1])
             show("first K-step produced", t[:, 3] - t[:, 2])
-            nk = min(ks, 20)
+            nk = min(ks, 16)
             for i in range(nk - 1):
                 show("K-step %d" % i, t[:, 5 + i] - t[:, 4 + i])
+            if int(os.environ.get("PLHIP_FUSED_DEBUG", "0")) & 64 and ks > 7:
+                show("  K-step 6: top -> counted vmcnt wait done", t[:, 20] - t[:, 10])
+                show("  K-step 6: lgkm wait + barrier", t[:, 21] - t[:, 20])
+                show("  K-step 6: tr reads, DMA, weight loads issued", t[:, 22] - t[:, 21])
+                show("  K-step 6: 8 MFMAs issued", t[:, 23] - t[:, 22])
+                show("  K-step 6: produce (reads, arithmetic, writes)", t[:, 24] - t[:, 23])
+                show("  K-step 6: -> next top", t[:, 11] - t[:, 24])
             show("last stamped K-step top -> loop end", t[:, 26] - t[:, 4 + nk - 1])
             show("whole loop", t[:, 26] - t[:, 4])
             show("scale/bias + requantise + stage", t[:, 27] - t[:, 26])
