@@ -124,3 +124,23 @@ def test_magic_division_is_exact_below_2_31():
         q = (ns >> np.uint64(sh)) if magic == 0 else (((ns * np.uint64(magic)) >> np.uint64(32)) >> np.uint64(sh))
         assert np.array_equal(q, ns // np.uint64(d)), d
 
+
+
+def test_fused_dwpw_support_query_is_host_only(pkg):
+    """plhip_dwpw_fused_supported is a pure function of the descriptors (no device): the stride-1 MobileNetV1 pairs fit the
+    fused path at batch 128 (the wide 56x56 tile narrows itself to fit the LDS), most stride-2 pairs do not (four K-steps
+    of their staged input rows exceed the LDS), 5x5 / dilated / non-depthwise convs never do, and an int8 output whose
+    OW % 4 == 1 (a compact output dword would span three quads) is refused while the fp32 one is taken."""
+    capi = pkg.capi
+    lib = capi.load()
+
+    def q(n, c, hw, s, m, out=capi.OUT_I8, k=3, groups=None, dil=1):
+        d = capi.conv_desc(n, c, hw, hw, c, k, k, (k // 2,) * 4, (s, s), (dil, dil), c if groups is None else groups, capi.ACT_RELU, 0.0)
+        return lib.plhip_dwpw_fused_supported(ctypes.byref(d), m, out)
+
+    for (c, hw, m) in [(32, 112, 64), (128, 56, 128), (256, 28, 256), (512, 14, 512), (1024, 7, 1024)]:
+        assert q(128, c, hw, 1, m) == 1, (c, hw, m)
+    assert q(128, 64, 112, 2, 128) == 0 and q(128, 512, 14, 2, 1024) == 0
+    assert q(128, 512, 14, 1, 512, k=5) == 0 and q(128, 512, 14, 1, 512, dil=2) == 0 and q(128, 512, 14, 1, 512, groups=1) == 0
+    assert q(4, 64, 13, 1, 64, out=capi.OUT_I8) == 0 and q(4, 64, 13, 1, 64, out=capi.OUT_F32) == 1
+    assert q(4, 2048, 14, 1, 64) == 0  # more channels than the parameter table holds
