@@ -263,9 +263,10 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
                                              int ch, int oy0, int xq, bool live, long gid_in, uint8_t* wlds);
 
 template <int OUT, int S, int RS, bool TAIL, bool STAGE>
-__device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, uint8_t* wlds) {
-  const bool live = gid_in < a.total_lanes;
-  const long gid = live ? gid_in : a.total_lanes - 1;
+__device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, bool live, uint8_t* wlds) {
+  // a dead lane (staging: the surplus lanes of a wave, the lanes past the end) recomputes its wave's FIRST quad: a live
+  // one by the kernel's wave-level exit test, and inside whatever part of the tensor this workgroup's fetch variant is safe for
+  const long gid = live ? gid_in : gid_in - (threadIdx.x & 63);
   constexpr int NIN = (RS - 1) * S + 3;  // input rows per strip
   constexpr int ND = S == 1 ? 2 : 3;     // dwords per row load
   const int owq = (a.ow + 3) >> 2;
@@ -387,7 +388,9 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
     }
 #undef DW_PK
     const int lane = threadIdx.x & 63;
-    const int strip_l = lane >> a.owq_log2;              // strip index inside the wave
+    const int owq_s = (a.ow + 3) >> 2;
+    // strip index inside the wave (a wave owns lw / owq whole strips; lw = 64 when owq is a power of two)
+    const int strip_l = a.owq_log2 >= 0 ? (lane >> a.owq_log2) : (int)fastdiv_u31((uint32_t)lane, a.div_owq_m, a.div_owq_s);
     const int lofs = strip_l * (RS * a.ow) + 4 * xq;     // byte offset of (row 0, quad) inside the wave's region
     if (live) {
       if ((a.ow & 1) == 0) {
@@ -410,11 +413,12 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
       }
     }
     // the wave's region in global memory starts at the output offset of its lane 0
-    const long gid0 = gid_in - lane;
-    const long strip0 = gid0 >> a.owq_log2;
+    const long gid0 = gid_in - lane;  // a multiple of owq
+    const long strip0 = a.owq_log2 >= 0 ? (gid0 >> a.owq_log2) : (long)fastdiv_u31((uint32_t)gid0, a.div_owq_m, a.div_owq_s);
     const size_t wbase = (size_t)strip0 * (RS * a.ow);
     const long lanes_left = a.total_lanes - gid0;
-    const int nstrips = (int)((lanes_left < 64 ? lanes_left : 64) >> a.owq_log2);
+    const int lanes_mine = (int)(lanes_left < a.lw ? lanes_left : a.lw);
+    const int nstrips = a.owq_log2 >= 0 ? (lanes_mine >> a.owq_log2) : lanes_mine / owq_s;
     const int region = nstrips * RS * a.ow;  // bytes
     int8_t* yb = reinterpret_cast<int8_t*>(a.y) + wbase;
     if ((((uintptr_t)yb | (uintptr_t)region) & 15) == 0) {
@@ -458,9 +462,10 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
 // large layers ran at 94 % VALU issue -- this op is VALU-bound before it is HBM-bound.)  The first workgroup (a window
 // may start before the tensor) and the last ones (it may end after it) use the guarded general body instead.
 template <int OUT, int S, int RS, bool STAGE>
-__device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, uint8_t* wlds) {
-  const bool live = gid_in < a.total_lanes;
-  const long gid = live ? gid_in : a.total_lanes - 1;
+__device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, bool live, uint8_t* wlds) {
+  // a dead lane (staging: the surplus lanes of a wave, the lanes past the end) recomputes its wave's FIRST quad: a live
+  // one by the kernel's wave-level exit test, and inside whatever part of the tensor this workgroup's fetch variant is safe for
+  const long gid = live ? gid_in : gid_in - (threadIdx.x & 63);
   constexpr int NIN = (RS - 1) * S + 3;
   constexpr int ND = S == 1 ? 2 : 3;
   const int owq = (a.ow + 3) >> 2;
@@ -515,25 +520,29 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
   PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.wt); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias);
   PLHIP_PRELOAD(a.planes); PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.h); PLHIP_PRELOAD(a.w); PLHIP_PRELOAD(a.oh); PLHIP_PRELOAD(a.ow);
   PLHIP_PRELOAD(a.pt); PLHIP_PRELOAD(a.pl); PLHIP_PRELOAD(a.total_lanes); PLHIP_PRELOAD(a.owq_log2); PLHIP_PRELOAD(a.spp_log2);
-  PLHIP_PRELOAD(a.fast_div); PLHIP_PRELOAD(a.stage_bytes); PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha);
+  PLHIP_PRELOAD(a.fast_div); PLHIP_PRELOAD(a.stage_bytes); PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha); PLHIP_PRELOAD(a.lw); PLHIP_PRELOAD(a.nblocks);
   PLHIP_PRELOAD(a.div_owq_m); PLHIP_PRELOAD(a.div_spp_m); PLHIP_PRELOAD(a.div_c_m); PLHIP_PRELOAD(a.div_owq_s); PLHIP_PRELOAD(a.div_spp_s); PLHIP_PRELOAD(a.div_c_s);
   extern __shared__ __attribute__((aligned(16))) uint8_t dw_stage[];  // STAGE: 4 waves x stage_bytes
   // XCD-contiguous work: workgroups are dealt round-robin over the 8 XCDs (private L2 each); giving XCD x the x-th eighth
   // of the lane space keeps neighbouring strips (which share their 2 halo rows and the cache lines at their edges) on
   // one L2 (PMC: FETCH x2 was 1.3x the input bytes with consecutive blocks on consecutive XCDs).  grid = 8 * per blocks.
-  const unsigned nb = (unsigned)((a.total_lanes + 255) >> 8), per = (nb + 7) >> 3;
+  const unsigned nb = (unsigned)a.nblocks, per = (nb + 7) >> 3;
   const unsigned vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (vb >= nb) return;
-  long gid = (long)vb * 256 + threadIdx.x;
+  // STAGE: a wave owns lw = (64 / owq) * owq lanes = whole strips (lw = 64 when owq divides 64; 63 for 28-wide, 56 for
+  // 56-wide planes): the 64 - lw surplus lanes compute nothing and only help with the cooperative copy-out
+  const int lane_w = threadIdx.x & 63;
+  long gid = STAGE ? (long)(vb * 4 + (threadIdx.x >> 6)) * a.lw + lane_w : (long)vb * 256 + threadIdx.x;
   if (!STAGE && gid >= a.total_lanes) return;
-  // STAGE: lanes past the end stay (they help with the cooperative copy-out) but are wave-uniformly dropped when the
-  // whole wave is past the end; a dead lane recomputes the last live quad and skips its LDS writes
-  if (STAGE && gid - (threadIdx.x & 63) >= a.total_lanes) return;
+  // STAGE: lanes past the end stay (copy-out) but are wave-uniformly dropped when the whole wave is past the end; a dead
+  // lane recomputes the last live quad and skips its LDS writes
+  if (STAGE && gid - lane_w >= a.total_lanes) return;
+  const bool live = STAGE ? (lane_w < a.lw && gid < a.total_lanes) : true;
   uint8_t* wlds = STAGE ? dw_stage + (threadIdx.x >> 6) * a.stage_bytes : nullptr;
   // only the last workgroups can touch the final bytes of the tensor: they alone pay for the guarded loads
-  if (vb + 4 >= nb) dw3x3_direct_body<OUT, S, RS, true, STAGE>(a, gid, wlds);
-  else if (FASTV && vb != 0) dw3x3_fast_body<OUT, S, RS, STAGE>(a, gid, wlds);
-  else dw3x3_direct_body<OUT, S, RS, false, STAGE>(a, gid, wlds);
+  if (vb + 4 >= nb) dw3x3_direct_body<OUT, S, RS, true, STAGE>(a, gid, live, wlds);
+  else if (FASTV && vb != 0) dw3x3_fast_body<OUT, S, RS, STAGE>(a, gid, live, wlds);
+  else dw3x3_direct_body<OUT, S, RS, false, STAGE>(a, gid, live, wlds);
 }
 
 template <int OUT, int S>
@@ -541,7 +550,6 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
   const long owq = (a_in.ow + 3) >> 2;
   const long spp = (a_in.oh + rs - 1) / rs;
   const long total = (long)a_in.planes * spp * owq;
-  const unsigned blocks = (unsigned)(((total + 255) / 256 + 7) / 8 * 8);  // 8 XCDs x equal shares (kernel: vb map)
   DwArgs a = a_in;
   a.total_lanes = total;
   auto lg2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return (1L << l) == v ? l : -1; };
@@ -565,7 +573,21 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
     const char* e = getenv("PLHIP_DW_STAGE");
     stage_env = e ? atoi(e) : 1;
   }
-  const bool stage = stage_env && OUT == OUT_I8 && a.ow <= 64 && a.owq_log2 >= 0 && owq <= 64 && a.oh % rs == 0;
+  // (owq a power of two: a wave = 64 lanes = whole strips; otherwise a wave uses (64 / owq) * owq lanes: 63 of 64 on
+  // 28-wide planes, 56 of 64 on 56-wide ones — the 14x14 layers went 19.3 -> 11.0 us with staging, and a 28x28 layer
+  // moves the same bytes with the same arithmetic)
+  static int stage_np2 = -1;
+  if (stage_np2 < 0) {
+    const char* e = getenv("PLHIP_DW_STAGE_NP2");
+    stage_np2 = e ? atoi(e) : 1;
+  }
+  // measured: 28-wide planes gain ~5 % (dw6 19.7 -> 18.7 us), 56-wide ones lose ~5 %: the store-request granularity that
+  // staging cures is a narrow-row effect; stage_np2 = 2 forces it for every width <= 64
+  const bool stage = stage_env && OUT == OUT_I8 && a.ow <= 64 && owq <= 64 && a.oh % rs == 0 &&
+                     (a.owq_log2 >= 0 || (stage_np2 == 1 && a.ow <= 32) || stage_np2 >= 2);
+  a.lw = stage ? (int)((64 / owq) * owq) : 64;
+  a.nblocks = stage ? (int)(((total + a.lw - 1) / a.lw + 3) / 4) : (int)((total + 255) / 256);
+  const unsigned blocks = (unsigned)((a.nblocks + 7) / 8 * 8);  // 8 XCDs x equal shares (kernel: vb map)
   a.stage_bytes = stage ? (int)(((64 / owq) * rs * a.ow + 15) & ~15) : 0;
   const size_t lds = stage ? (size_t)4 * a.stage_bytes : 0;
   // fast row fetch: only the first / last row of a strip can leave the image, windows start inside the row

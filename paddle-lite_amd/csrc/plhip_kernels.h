@@ -77,6 +77,7 @@ struct DwArgs {
   unsigned div_owq_m, div_spp_m, div_c_m;
   int div_owq_s, div_spp_s, div_c_s;
   int stage_bytes;                // direct kernel: LDS bytes per wave for output staging (0 = off)
+  int lw, nblocks;                // direct kernel: lanes of a wave that own work (staging: whole strips), workgroups of work
   int act;
   float alpha;
 };
