@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "gemm_epilogue.h"
+#include "dw_common.h"
 
 namespace plhip {
 
@@ -1022,10 +1023,12 @@ __global__ void pad_input_i8_kernel(PadArgs a) {
   const long nq = a.total >> 2;
   const int plane_sz = a.ph * a.pw;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
-    const uint32_t o = (uint32_t)q << 2;  // the padded buffer is < 2^31 bytes (conv_geom): 32-bit divisions
-    int plane = (int)(o / (uint32_t)plane_sz);
+    // the padded buffer is < 2^31 bytes (conv_geom): magic-number divisions (two hardware divide sequences per dword made
+    // this copy VALU-bound: 35 us for ResNet50's 55 MB res2 planes)
+    const uint32_t o = (uint32_t)q << 2;
+    int plane = (int)fastdiv_u31(o, a.div_plane_m, a.div_plane_s);
     const int rem = (int)(o - (uint32_t)plane * (uint32_t)plane_sz);
-    int ph = (int)((uint32_t)rem / (uint32_t)a.pw), pw = rem - ph * a.pw;
+    int ph = (int)fastdiv_u31((uint32_t)rem, a.div_pw_m, a.div_pw_s), pw = rem - ph * a.pw;
     uint32_t v = 0;
     {  // interior dword (the common case): one unaligned 4-byte load
       const int ih = ph - a.pt, iw = pw - a.pl;
@@ -1058,12 +1061,13 @@ __global__ void pad_input_phase2_i8_kernel(PadArgs a) {
   const long nq = a.total >> 2;
   const int pwq = a.pw >> 2;  // launcher: phase rows are padded to a multiple of 4 columns
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
-    const int xq = (int)(q % pwq);
-    long t = q / pwq;
-    const int y = (int)(t % a.ph);
-    t /= a.ph;
-    const int ph = (int)(t & 3);
-    const long plane = t >> 2;
+    // q < 2^29 (the buffer is < 2^31 bytes): 32-bit magic-number divisions, no 64-bit divide sequences
+    const uint32_t t1 = fastdiv_u31((uint32_t)q, a.div_pwq_m, a.div_pwq_s);
+    const int xq = (int)((uint32_t)q - t1 * (uint32_t)pwq);
+    const uint32_t t2 = fastdiv_u31(t1, a.div_ph_m, a.div_ph_s);
+    const int y = (int)(t1 - t2 * (uint32_t)a.ph);
+    const int ph = (int)(t2 & 3);
+    const long plane = (long)(t2 >> 2);
     uint32_t v = 0;
     if (plane < a.planes) {
       const int iy = 2 * y + (ph >> 1) - a.pt;
@@ -1080,7 +1084,24 @@ __global__ void pad_input_phase2_i8_kernel(PadArgs a) {
   }
 }
 
-void launch_pad_input(const PadArgs& a, hipStream_t s) {
+static void pad_magic(long d, unsigned& m, int& sh) {  // fastdiv_u31's (magic, shift) for divisor d (dw_common.h)
+  int l = 0;
+  while ((1L << l) < d) ++l;
+  if ((1L << l) == d) {
+    m = 0;
+    sh = l;
+    return;
+  }
+  m = (unsigned)(((1ULL << (31 + l)) / (unsigned long long)d) + 1ULL);
+  sh = l - 1;
+}
+
+void launch_pad_input(const PadArgs& a_in, hipStream_t s) {
+  PadArgs a = a_in;
+  pad_magic((long)a.ph * a.pw, a.div_plane_m, a.div_plane_s);
+  pad_magic(a.pw, a.div_pw_m, a.div_pw_s);
+  pad_magic(a.pw >> 2 > 0 ? a.pw >> 2 : 1, a.div_pwq_m, a.div_pwq_s);
+  pad_magic(a.ph, a.div_ph_m, a.div_ph_s);
   if (a.stride == 2) {
     long blocks2 = ((a.total >> 2) + 255) / 256;
     if (blocks2 > 65536) blocks2 = 65536;

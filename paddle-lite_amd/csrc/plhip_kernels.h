@@ -47,6 +47,10 @@ struct PadArgs {
   int planes, h, w, ph, pw, pt, pl;
   int stride;       // 1, or 2 = phase-split copy (ph, pw are then the phase plane's dims)
   long total;       // bytes of xp to write (multiple of 4: planes*ph*pw rounded up + slack)
+  // exact division of a 31-bit index by ph*pw and by pw without a divide sequence (launch_pad_input fills them; same
+  // (magic, shift) form as DwArgs: magic == 0 -> power of two)
+  unsigned div_plane_m, div_pw_m, div_pwq_m, div_ph_m;  // pwq = pw / 4 and ph: the phase-split copy's divisors
+  int div_plane_s, div_pw_s, div_pwq_s, div_ph_s;
 };
 void launch_pad_input(const PadArgs& a, hipStream_t s);
 
