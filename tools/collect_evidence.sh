@@ -12,7 +12,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_default -o p --ou
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_serial -o p --output-format csv -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 30 > $O/bench_under_rocprof_serial.json 2> $O/stats_serial.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 3 --warmup 1 > /dev/null 2> $O/fetch.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 3 --warmup 1 > /dev/null 2> $O/write.err || exit 1
+# where the waves' cycles go: one SQ counter pass (8 SQ slots), serial form, aggregated per kernel by tools/pmc_sq.py
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/sq_c3 -o s --output-format csv -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 3 --warmup 1 > /dev/null 2> $O/sq_c3.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/sq_c4 -o s --output-format csv -- python $R/bench.py --config c4 --no-cpu-baseline --inflight 1 --steps 2 --warmup 1 > /dev/null 2> $O/sq_c4.err || exit 1
 cd $R
+python tools/pmc_sq.py $O/sq_c3 $O/pmc_sq_c3.csv > /dev/null || exit 1
+python tools/pmc_sq.py $O/sq_c4 $O/pmc_sq_c4.csv > /dev/null || exit 1
 timeout -k 10 200 python tools/opbench.py all 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench.txt || exit 1
 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/gemm_timeline.py pw8 > $O/gemm_timeline_pw8.txt 2>&1 || exit 1
 timeout -k 10 400 python bench.py --layer-table > $O/bench.json 2> $O/layer_table.txt || exit 1
@@ -28,7 +33,8 @@ PLHIP_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $
 # per-layer tables at batch 256, the fused depthwise -> pointwise pairs, and their timelines
 timeout -k 10 200 python tools/opbench.py all --batch 256 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench_b256.txt || exit 1
 timeout -k 10 200 python tools/opbench.py fused --batch 128 2>&1 | cut -c1-110 > $O/opbench_fused.txt || exit 1
-PLHIP_FUSED_DEBUG=32 timeout -k 10 100 python tools/fused_timeline.py dw8 > $O/fused_timeline_dw8.txt 2>&1 || exit 1
+PLHIP_FUSED_DEBUG=96 timeout -k 10 100 python tools/fused_timeline.py dw8 > $O/fused_timeline_dw8.txt 2>&1 || exit 1
+timeout -k 10 120 python tools/fused_concurrency.py --threads 3 > $O/fused_concurrency.txt 2>&1 || exit 1
 PLHIP_GEMM_TR=2 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/gemm_timeline.py pw8 --tr > $O/gemm_tr_timeline_pw8.txt 2>&1 || exit 1
 timeout -k 10 100 python tools/c2bench.py > $O/c2bench.txt 2>&1 || exit 1
 tail -c 300 $O/bench.json

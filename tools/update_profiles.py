@@ -29,7 +29,8 @@ cp("bench.json", "bench.json")
 cp("bench_inflight1.json", "bench_inflight1.json")
 cp("gemm_timeline_pw8.txt", "gemm_timeline_pw8.txt")
 for f in ("bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.json", "layer_table_c4.txt", "layer_table_c5.txt",
-          "opbench_b256.txt", "opbench_fused.txt", "fused_timeline_dw8.txt", "gemm_tr_timeline_pw8.txt", "c2bench.txt"):
+          "opbench_b256.txt", "opbench_fused.txt", "fused_timeline_dw8.txt", "gemm_tr_timeline_pw8.txt", "c2bench.txt",
+          "pmc_sq_c3.csv", "pmc_sq_c4.csv", "fused_concurrency.txt"):
     if os.path.exists(os.path.join(E, f)):
         cp(f, f)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
