@@ -131,7 +131,7 @@ class HipEngine:
                                0.0, float(o["in_scale"]), o["w_scale"], float(o["out_scale"]), True)
             self.out_var, self.plan = o["name"], None
         else:
-            wl.emit_graph(self.pred, net, rows)
+            wl.emit_graph(self.pred, net, rows, fuse_dwpw=os.environ.get("PLHIP_BENCH_FUSE_DWPW", "0") == "1")
             self.plan = self.pred.graph_plan()
             self.pred.graph_lower()
             self.out_var = net["output"]

@@ -180,6 +180,30 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
     dead[i] = true;
     st[pc].drop_f32 = uses(st[pc].out) == 0;
   }
+  // (D) opt-in: depthwise_conv2d[int8_out] whose only consumer is a plain 1x1 conv (no tail of its own) takes it over
+  if (fuse_dwpw_) {
+    for (size_t i = 0; i < st.size(); ++i) {
+      if (dead[i] || st[i].kind != "op" || ops_[st[i].op].type != "depthwise_conv2d" || !st[i].int8_out || st[i].pw_op >= 0) continue;
+      if (uses(st[i].out) != 1) continue;
+      int j = -1;
+      for (size_t t = 0; t < st.size(); ++t)
+        if (!dead[t] && st[t].kind == "op" && !st[t].op_inputs.empty() && st[t].op_inputs[0] == st[i].out) j = static_cast<int>(t);
+      if (j < 0) continue;
+      const GraphOp& c = ops_[st[j].op];
+      if (c.type != "conv2d" || !c.enable_int8 || c.w_dims.size() != 4 || c.w_dims[2] != 1 || c.w_dims[3] != 1 || c.conv.groups != 1 ||
+          c.conv.strides != std::vector<int>({1, 1}) || c.conv.dilations != std::vector<int>({1, 1}))
+        continue;
+      bool pad0 = true;
+      for (int v : c.conv.paddings) pad0 = pad0 && v == 0;
+      if (!pad0 || !st[j].res.empty() || !st[j].calib_out.empty() || st[j].drop_f32) continue;
+      st[i].pw_op = st[j].op;
+      st[i].pw_int8_out = st[j].int8_out;
+      st[i].pw_out_scale = st[j].out_scale;
+      st[i].via = st[i].out;
+      st[i].out = st[j].out;
+      dead[j] = true;
+    }
+  }
   std::vector<Step> kept;
   for (size_t i = 0; i < st.size(); ++i)
     if (!dead[i]) kept.push_back(st[i]);
@@ -216,6 +240,13 @@ std::vector<std::string> GraphBuilder::Plan() {
       }
       if (s.drop_f32) l += " -f32";
       if (s.pool_int8) l += " int8";
+      if (s.pw_op >= 0) {
+        l += std::string(" +pw=conv2d/") + (s.pw_int8_out ? "int8_out" : "fp32_out") + " via=" + s.via;
+        if (s.pw_int8_out) {
+          snprintf(buf, sizeof buf, " pw_oscale=%.9g", s.pw_out_scale);
+          l += buf;
+        }
+      }
     } else {
       l = s.kind == "io_copy_h2d" ? "io_copy/host_to_device"
           : s.kind == "io_copy_d2h" ? "io_copy/device_to_host"
@@ -256,6 +287,17 @@ std::vector<std::string> GraphBuilder::Lower(HipPredictor* pred) {
         a.calib_out = s.calib_out;
         a.calib_scale = s.calib_scale;
         a.drop_fp32 = s.drop_f32;
+        if (s.pw_op >= 0) {
+          const GraphOp& c = ops_[s.pw_op];
+          a.pw_w = c.w.data();
+          a.pw_w_dims = c.w_dims;
+          a.pw_bias = c.has_bias ? c.bias.data() : nullptr;
+          a.pw_weight_scale = c.conv.weight_scale;
+          a.pw_output_scale = s.pw_int8_out ? s.pw_out_scale : 1.f;
+          a.pw_int8_out = s.pw_int8_out;
+          a.pw_act = c.conv.act;
+          a.pw_act_coef = c.conv.act_coef;
+        }
         pred->AddConv(op.type, s.op_inputs[0], s.out, op.w.data(), op.w_dims, op.has_bias ? op.bias.data() : nullptr, a);
       } else if (op.type == "fc") {
         CHECK(op.enable_int8) << "kHIP has int8 fc kernels only";

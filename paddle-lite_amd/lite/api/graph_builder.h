@@ -53,6 +53,9 @@ class GraphBuilder {
   //   conv2d[fp32_out] -> elementwise_add | fusion_elementwise_add_activation(relu) -> calib   => ONE conv launch
   //   conv2d[fp32_out] -> pool2d(max) -> calib                                  => conv + fused calib, int8 max pool
   void set_fuse(bool on) { fuse_ = on; }
+  // Opt-in (off by default: the fused kernel is exact but, measured, not faster than the two kernels — DESIGN.md 8):
+  //   depthwise_conv2d[int8_out] -> conv2d 1x1 (stride 1, no padding, groups 1, no fused tail), sole consumer  => ONE instruction
+  void set_fuse_dwpw(bool on) { fuse_dwpw_ = on; }
   GraphOp& Add(const std::string& type, const std::vector<std::string>& inputs, const std::string& output);
   // Emits the program into `pred`; returns the host-side names of the fetched variables ("<name>/host").
   std::vector<std::string> Lower(HipPredictor* pred);
@@ -77,6 +80,10 @@ class GraphBuilder {
     float calib_scale{1.f};
     bool drop_f32{false};     // the fp32 output has no consumer left
     bool pool_int8{false};    // pool2d(max) moved behind the calib: max commutes with the monotonic quantiser
+    int pw_op{-1};            // depthwise conv that took its 1x1 consumer over: index of that conv in ops_
+    bool pw_int8_out{true};
+    float pw_out_scale{1.f};
+    std::string via;          // name the depthwise result would have had
   };
   std::vector<Step> Schedule();
   void FuseSteps(std::vector<Step>* steps);
@@ -86,6 +93,7 @@ class GraphBuilder {
     PrecisionType prec;
   };
   bool fuse_{true};
+  bool fuse_dwpw_{false};
   std::vector<FeedDesc> feeds_;
   std::vector<std::string> fetches_;
   std::vector<GraphOp> ops_;

@@ -111,6 +111,23 @@ void HipPredictor::AddConv(const std::string& op_type, const std::string& in, co
     p.calib_scale = a.calib_scale;
     p.drop_fp32_output = a.drop_fp32;
   }
+  if (a.pw_w) {
+    CHECK(a.int8_out && op_type == "depthwise_conv2d") << "only a depthwise conv with int8 output takes a 1x1 consumer over";
+    size_t pn = 1;
+    for (auto d : a.pw_w_dims) pn *= static_cast<size_t>(d);
+    p.pw_filter = NewParam(a.pw_w, pn, a.pw_w_dims, PRECISION(kInt8));
+    p.pw_bias = a.pw_bias ? NewParam(a.pw_bias, static_cast<size_t>(a.pw_w_dims[0]) * 4, {a.pw_w_dims[0]}, PRECISION(kFloat)) : nullptr;
+    p.pw_weight_scale = a.pw_weight_scale;
+    p.pw_output_scale = a.pw_output_scale;
+    p.pw_int8_out = a.pw_int8_out;
+    if (a.pw_act != 0) {
+      p.pw_activation_param.has_active = true;
+      p.pw_activation_param.active_type = static_cast<lite_api::ActivationType>(a.pw_act);
+      if (a.pw_act == 2) p.pw_activation_param.Relu_clipped_coef = a.pw_act_coef;
+      if (a.pw_act == 4) p.pw_activation_param.Leaky_relu_alpha = a.pw_act_coef;
+    }
+    p.output->set_precision(a.pw_int8_out ? PRECISION(kInt8) : PRECISION(kFloat));
+  }
   op->set_padding_algorithm(a.padding_algorithm);
   Emit(op, PickKernel(op_type, Place(TARGET(kHIP), PRECISION(kInt8)), a.int8_out ? "int8_out" : "fp32_out"));
 }

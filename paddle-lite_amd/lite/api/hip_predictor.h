@@ -35,6 +35,15 @@ struct ConvAttrs {
   std::string residual, calib_out;
   bool residual_relu{false}, drop_fp32{false};
   float calib_scale{1.f};
+  // kHIP fused 1x1 consumer of a depthwise conv (ConvParam::pw_*): `out` of AddConv is then the pointwise conv's output
+  const int8_t* pw_w{nullptr};
+  std::vector<int64_t> pw_w_dims;
+  const float* pw_bias{nullptr};
+  std::vector<float> pw_weight_scale;
+  float pw_output_scale{1.f};
+  bool pw_int8_out{true};
+  int pw_act{0};
+  float pw_act_coef{0.f};
 };
 
 class HipPredictor {

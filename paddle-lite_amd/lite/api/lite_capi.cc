@@ -192,6 +192,9 @@ int pllite_graph_softmax(pllite_predictor* p, const char* in, const char* out) {
 int pllite_graph_set_fuse(pllite_predictor* p, int on) {
   return guarded([&] { p->graph.set_fuse(on != 0); });
 }
+int pllite_graph_set_fuse_dwpw(pllite_predictor* p, int on) {
+  return guarded([&] { p->graph.set_fuse_dwpw(on != 0); });
+}
 int pllite_graph_fetch(pllite_predictor* p, const char* name) {
   return guarded([&] { p->graph.Fetch(name); });
 }

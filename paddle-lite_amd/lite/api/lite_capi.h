@@ -55,6 +55,8 @@ int pllite_graph_softmax(pllite_predictor* p, const char* in, const char* out);
 int pllite_graph_fetch(pllite_predictor* p, const char* name);
 /* kHIP graph-level fusions (graph_builder.h set_fuse): on by default; 0 = the reference program instruction for instruction. */
 int pllite_graph_set_fuse(pllite_predictor* p, int on);
+// opt-in: depthwise_conv2d[int8_out] -> sole consumer conv2d 1x1 as ONE instruction (GraphBuilder::set_fuse_dwpw)
+int pllite_graph_set_fuse_dwpw(pllite_predictor* p, int on);
 /* '\n'-separated plan (GraphBuilder::Plan) — needs no device. */
 int pllite_graph_plan(pllite_predictor* p, char* buf, int cap);
 /* Emit the program into the predictor; '\n'-separated host names of the fetched variables in buf. */

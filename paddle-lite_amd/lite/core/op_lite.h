@@ -79,7 +79,8 @@ class ConvOpLite : public OpLite {
   bool InferShapeImpl() const override {
     const auto in = param_.x->dims(), f = param_.filter->dims();
     UpdatePaddingAndDilation(param_.paddings.get(), param_.dilations.get(), param_.strides, padding_algorithm_, in, f);
-    std::vector<int64_t> out{in[0], f[0]};
+    // kHIP fusion: a depthwise conv that took its 1x1 consumer over writes THAT conv's output: pw_filter.dims[0] channels
+    std::vector<int64_t> out{in[0], param_.pw_filter ? param_.pw_filter->dims()[0] : f[0]};
     for (size_t i = 0; i < param_.strides.size(); ++i)
       out.push_back(ConvOutputSize(static_cast<int>(in[i + 2]), static_cast<int>(f[i + 2]), (*param_.dilations)[i],
                                    (*param_.paddings)[i * 2], (*param_.paddings)[i * 2 + 1], param_.strides[i]));

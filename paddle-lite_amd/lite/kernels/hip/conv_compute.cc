@@ -52,7 +52,72 @@ void ConvCompute<Ptype, OutType>::ReInitWhenNeeded() {
   if (last_shape_ == param.x->dims()) return;  // conv_gemmlike.cc:92 idiom
   BuildDesc();
   workspace_bytes_ = is_depthwise_ ? 0 : plhip_conv_workspace_bytes(&desc_);
+  if (has_pw_) {  // the pointwise conv sees the depthwise conv's output plane
+    const auto od = param.output->dims();
+    pw_desc_.n = desc_.n;
+    pw_desc_.h = static_cast<int>(od[2]);
+    pw_desc_.w = static_cast<int>(od[3]);
+    pw_fused_ = plhip_dwpw_fused_supported(&desc_, pw_desc_.cout, param.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32) != 0;
+    kernel_func_name_ = pw_fused_ ? "conv_depthwise_3x3_pointwise_1x1_fused_int8_hip" : "conv_depthwise_int8_hip+conv1x1s1_gemm_int8_mfma32x32x32";
+  }
   last_shape_ = param.x->dims();
+}
+
+// The 1x1 consumer taken over by a depthwise conv (graph_builder.cc, fusion D): folded exactly as ConvCompute folds a
+// stand-alone conv2d (conv_gemmlike.cc:208-263) with the depthwise output scale as its input scale.
+template <PrecisionType Ptype, PrecisionType OutType>
+void ConvCompute<Ptype, OutType>::PreparePointwise() {
+  auto& param = this->template Param<param_t>();
+  auto& ctx = this->ctx_->template As<HIPContext>();
+  CHECK(is_depthwise_ && OutType == PRECISION(kInt8)) << "kHIP: only a depthwise conv with int8 output takes a 1x1 consumer over";
+  const auto wd = param.pw_filter->dims();
+  CHECK(wd.size() == 4UL && wd[2] == 1 && wd[3] == 1 && wd[1] == desc_.cout) << "fused consumer must be a 1x1 conv over the depthwise channels";
+  const int m = static_cast<int>(wd[0]);
+  pw_desc_ = plhip_conv_desc{};
+  pw_desc_.n = desc_.n; pw_desc_.cin = desc_.cout; pw_desc_.h = 1; pw_desc_.w = 1; pw_desc_.cout = m;
+  pw_desc_.kh = pw_desc_.kw = 1;
+  pw_desc_.stride[0] = pw_desc_.stride[1] = 1;
+  pw_desc_.dil[0] = pw_desc_.dil[1] = 1;
+  pw_desc_.groups = 1;
+  const auto& act = param.pw_activation_param;
+  float alpha = 0.f;
+  pw_desc_.act = PLHIP_ACT_NONE;
+  if (act.has_active) {
+    switch (act.active_type) {
+      case lite_api::ActivationType::kRelu: pw_desc_.act = PLHIP_ACT_RELU; break;
+      case lite_api::ActivationType::kRelu6: pw_desc_.act = PLHIP_ACT_RELU6; alpha = act.Relu_clipped_coef; break;
+      case lite_api::ActivationType::kLeakyRelu: pw_desc_.act = PLHIP_ACT_LEAKY_RELU; alpha = act.Leaky_relu_alpha; break;
+      default: LOG(FATAL) << "this act_type: " << static_cast<int>(act.active_type) << " fuse not support";
+    }
+  }
+  std::vector<float> ws = param.pw_weight_scale;
+  if (ws.size() != 1 && ws.size() != static_cast<size_t>(m)) LOG(FATAL) << "weights scale size must equal to filter size";
+  if (ws.size() == 1) ws.resize(m, ws[0]);
+  const float in_scale = param.output_scale, out_scale = param.pw_output_scale;  // dw output scale = pw input scale
+  for (auto& v : ws) v = param.pw_int8_out ? v * in_scale / out_scale : v * in_scale;
+  pw_scale_.Resize({m});
+  TargetWrapperHip::MemcpySync(pw_scale_.mutable_data<float>(TARGET(kHIP)), ws.data(), m * sizeof(float), IoDirection::HtoD);
+  pw_has_bias_ = param.pw_bias != nullptr;
+  if (pw_has_bias_) {
+    CHECK_EQ(param.pw_bias->numel(), m) << "bias size must equal to filter number";
+    std::vector<float> b(m);
+    TargetCopy(TARGET(kHost), param.pw_bias->target(), b.data(), param.pw_bias->raw_data(), m * sizeof(float));
+    if (param.pw_int8_out)
+      for (auto& v : b) v = v / out_scale;
+    pw_bias_.Resize({m});
+    TargetWrapperHip::MemcpySync(pw_bias_.mutable_data<float>(TARGET(kHIP)), b.data(), m * sizeof(float), IoDirection::HtoD);
+  }
+  if (param.pw_int8_out && pw_desc_.act == PLHIP_ACT_RELU6) alpha = alpha / out_scale;
+  pw_desc_.act_alpha = alpha;
+  Tensor staged;
+  const size_t w_bytes = static_cast<size_t>(param.pw_filter->numel());
+  const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(param.pw_filter, &staged, w_bytes));
+  const size_t packed = plhip_conv_packed_weight_bytes(&pw_desc_);
+  CHECK_GT(packed, 0UL) << "invalid fused pointwise configuration";
+  void* d = pw_weights_.mutable_data(TARGET(kHIP), packed);
+  HIP_CALL(ctx.ctx(), plhip_pack_conv_weights(ctx.ctx(), &pw_desc_, w_dev, d));
+  ctx.Sync();  // `staged` dies at scope exit
+  has_pw_ = true;
 }
 
 template <PrecisionType Ptype, PrecisionType OutType>
@@ -136,6 +201,7 @@ void ConvCompute<Ptype, OutType>::PrepareForRun() {
     ctx.Sync();  // `staged` dies at scope exit
     kernel_func_name_ = plhip_conv_impl_name(&desc_);
   }
+  if (param.pw_filter) PreparePointwise();
   last_shape_ = DDim();
   ReInitWhenNeeded();
 }
@@ -151,7 +217,7 @@ void ConvCompute<Ptype, OutType>::Run() {
   void* y;
   plhip_out_kind kind;
   if (OutType == PRECISION(kInt8)) {
-    y = param.output->template mutable_data<int8_t>(TARGET(kHIP));
+    y = has_pw_ ? nullptr : param.output->template mutable_data<int8_t>(TARGET(kHIP));  // has_pw_: allocated below, by the pointwise conv's precision
     kind = PLHIP_OUT_I8;
   } else {
     // a fused tail may leave the fp32 tensor without consumers (drop_fp32_output): then it is never allocated
@@ -176,6 +242,22 @@ void ConvCompute<Ptype, OutType>::Run() {
     HIP_CALL(ctx.ctx(), plhip_conv2d_int8_fused(ctx.ctx(), &desc_, x, weights_.raw_data(), sc, bi,
                                                 param.drop_fp32_output ? nullptr : static_cast<float*>(y), res,
                                                 param.fuse_residual_relu ? 1 : 0, q, param.calib_scale, ws, workspace_bytes_));
+  } else if (is_depthwise_ && has_pw_) {
+    // `output` is the pointwise conv's tensor (ConvParam::pw_*); y above was allocated as int8: redo it for fp32
+    void* yo = param.pw_int8_out ? static_cast<void*>(param.output->template mutable_data<int8_t>(TARGET(kHIP)))
+                                 : static_cast<void*>(param.output->template mutable_data<float>(TARGET(kHIP)));
+    const plhip_out_kind ko = param.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32;
+    const float* psc = pw_scale_.data<float>();
+    const float* pbi = pw_has_bias_ ? pw_bias_.data<float>() : nullptr;
+    if (pw_fused_) {
+      HIP_CALL(ctx.ctx(), plhip_dwpw_fused_int8(ctx.ctx(), &desc_, x, weights_.data<int8_t>(), sc, bi, pw_desc_.cout,
+                                                pw_weights_.raw_data(), psc, pbi, pw_desc_.act, pw_desc_.act_alpha, yo, ko));
+    } else {  // shape outside the fused kernel: the two kernels, the depthwise result in a private tensor
+      mid_.Resize({desc_.n, desc_.cout, pw_desc_.h, pw_desc_.w});
+      int8_t* mid = mid_.mutable_data<int8_t>(TARGET(kHIP));
+      HIP_CALL(ctx.ctx(), plhip_depthwise_conv_int8(ctx.ctx(), &desc_, x, weights_.data<int8_t>(), sc, bi, mid, PLHIP_OUT_I8));
+      HIP_CALL(ctx.ctx(), plhip_conv2d_int8(ctx.ctx(), &pw_desc_, mid, pw_weights_.raw_data(), psc, pbi, yo, ko, nullptr, 0));
+    }
   } else if (is_depthwise_) {
     HIP_CALL(ctx.ctx(), plhip_depthwise_conv_int8(ctx.ctx(), &desc_, x, weights_.data<int8_t>(), sc, bi, y, kind));
   } else {

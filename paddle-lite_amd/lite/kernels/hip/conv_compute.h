@@ -36,6 +36,12 @@ class ConvCompute : public KernelLite<TARGET(kHIP), Ptype> {
   float act_alpha_{0.f};
   size_t workspace_bytes_{0};
   std::string kernel_func_name_{"NotImplForConv"};
+  // fused 1x1 consumer of a depthwise conv (ConvParam::pw_*): its descriptor, packed weights, folded scale / bias; `mid_`
+  // holds the depthwise result only when the shape is outside the fused kernel and the two kernels run instead
+  void PreparePointwise();
+  bool has_pw_{false}, pw_fused_{false}, pw_has_bias_{false};
+  plhip_conv_desc pw_desc_{};
+  Tensor pw_weights_, pw_scale_, pw_bias_, mid_;
 };
 
 }  // namespace hip

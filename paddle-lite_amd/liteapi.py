@@ -53,6 +53,7 @@ def load():
     L.pllite_graph_softmax.argtypes = [vp, cs, cs]
     L.pllite_graph_fetch.argtypes = [vp, cs]
     L.pllite_graph_set_fuse.argtypes = [vp, i32]
+    L.pllite_graph_set_fuse_dwpw.argtypes = [vp, i32]
     L.pllite_graph_plan.argtypes = [vp, cs, i32]
     L.pllite_graph_lower.argtypes = [vp, cs, i32]
     L.pllite_load_model.argtypes = [vp, vp, i64, i32]
@@ -192,6 +193,11 @@ class Predictor:
 
     def graph_set_fuse(self, on):
         self._ck(self.L.pllite_graph_set_fuse(self.h, int(on)))
+
+    def graph_set_fuse_dwpw(self, on):
+        """Opt-in: a depthwise conv [int8_out] takes its sole 1x1 consumer over (one instruction, one launch where the
+        shape fits the fused kernel)."""
+        self._ck(self.L.pllite_graph_set_fuse_dwpw(self.h, int(on)))
 
     def graph_fetch(self, name):
         self._ck(self.L.pllite_graph_fetch(self.h, name.encode()))

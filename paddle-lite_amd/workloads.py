@@ -270,11 +270,12 @@ def net_stats(net):
     return macs
 
 
-def emit_graph(pred, net, batch, fuse=True):
+def emit_graph(pred, net, batch, fuse=True, fuse_dwpw=False):
     """Feed the op list to the predictor's graph mode and lower it.  Returns the host name of the output variable.
     fuse=False: the reference program instruction for instruction (no kHIP graph-level fusion)."""
     from . import liteapi
     pred.graph_set_fuse(fuse)
+    pred.graph_set_fuse_dwpw(fuse_dwpw)
     c, h, w = net["input_shape"]
     pred.graph_feed(net["input"], (batch, c, h, w), liteapi.PREC_FLOAT)
     for o in net["ops"]:
@@ -350,6 +351,16 @@ def program_costs(net, batch, plan_lines):
                 else:
                     fam = "stem_conv" if cin <= 4 else "conv%dx%d" % (k, k)
             byts = sum(numel(i) * esz[i] for i in ins) + wbytes
+            if "+pw" in kv:       # opt-in fusion: this depthwise conv took its 1x1 consumer over: `dst` is that conv's output
+                o2 = next(int8_ops)
+                assert o2["op"] == "conv2d" and o2["name"] == dst, (o2["name"], line)
+                esz[dst] = 1 if kv["+pw"].endswith("int8_out") else 4
+                m2, c2 = o2["w"].shape[0], o2["w"].shape[1]
+                _, h2, w2 = shapes[dst]
+                macs += batch * h2 * w2 * m2 * c2
+                wbytes += int(o2["w"].size)
+                byts += int(o2["w"].size)
+                fam = "dwpw_fused"
             if "-f32" not in flags:
                 byts += numel(dst) * esz[dst]
             if "+add" in kv:      # fused residual operand (fp32)

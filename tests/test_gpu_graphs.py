@@ -102,10 +102,10 @@ def test_fc_kernel_classes_pick_the_reference_route(lite, plref):
         assert np.array_equal(y, ref), (ws.size, int8_out)
 
 
-def _run_graph(lite, wl, net, img, fuse=False):
+def _run_graph(lite, wl, net, img, fuse=False, fuse_dwpw=False):
     p = lite.Predictor(0)
     try:
-        out = wl.emit_graph(p, net, img.shape[0], fuse=fuse)
+        out = wl.emit_graph(p, net, img.shape[0], fuse=fuse, fuse_dwpw=fuse_dwpw)
         fetched = p.graph_lower()
         assert fetched == [out]
         p.set_input(net["input"], img)
@@ -359,3 +359,43 @@ def test_int8_max_pool_commutes_with_calib(gpu_ctx, plref):
         xi = rng.integers(-128, -100, (2, 3, h, w)).astype(np.int8) if h == 15 else rng.integers(-127, 128, (2, 3, h, w)).astype(np.int8)
         want = plref.pool2d(xi.astype(np.float32), "max", (k, k), (s, s), pads).astype(np.int8)
         assert np.array_equal(gpu_ctx.pool2d(xi, "max", (k, k), (s, s), pads), want)
+
+
+@pytest.mark.parametrize("which,batch", [("mobilenet_v1", 2), ("mobilenet_v1", 9), ("mobilenet_v2", 3)])
+def test_opt_in_dwpw_fusion_equals_the_oracle_graph(lite, wl, plref, which, batch):
+    """GraphBuilder::set_fuse_dwpw through the predictor and the kernel class: a depthwise conv takes its 1x1 consumer
+    over (ConvParam::pw_*).  Where the shape fits, ONE launch of plhip_dwpw_fused_int8 (the stride-1 pairs), else the two
+    kernels inside the one instruction (the stride-2 pairs; at these small batches also the tiles touching > 4 images).
+    Every variable the program still produces equals the oracle's: int8 bit for bit, fp32 within 1e-5."""
+    net = wl.mobilenet_v1_net() if which == "mobilenet_v1" else wl.mobilenet_v2_net()
+    img = np.random.default_rng(350 + batch).uniform(-1, 1, (batch, 3, 224, 224)).astype(np.float32)
+    ref = graph_oracle.forward(plref, net, img)
+    p, out = _run_graph(lite, wl, net, img, fuse=True, fuse_dwpw=True)
+    try:
+        plan = p.graph_plan()
+        fused_lines = [l for l in plan if "+pw=" in l]
+        assert len(fused_lines) == (13 if which == "mobilenet_v1" else 2)
+        names = p.kernel_names()
+        n_one_launch = sum("conv_depthwise_3x3_pointwise_1x1_fused" in n for n in names)
+        n_two = sum("conv_depthwise_int8_hip+conv1x1s1" in n for n in names)
+        assert n_one_launch + n_two == len(fused_lines) and n_one_launch >= 1, names
+        gone = {l.split(" via=")[1].split(" ")[0] for l in fused_lines}
+        n_i8 = 0
+        for l in plan:
+            if not (l.startswith("conv2d/") or l.startswith("depthwise_conv2d/")):
+                continue
+            name = l.split(" out=")[1].split(" ")[0]
+            assert name not in gone
+            if " -f32" in l:
+                continue
+            want = ref[name]
+            got = p.get_var(name, want.dtype)
+            if want.dtype == np.int8:
+                assert np.array_equal(got, want), "%s: %d of %d int8 values differ" % (name, (got != want).sum(), want.size)
+                n_i8 += 1
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=name)
+        assert n_i8 >= 10
+        np.testing.assert_allclose(p.get_var(out, np.float32), ref["prob"], rtol=1e-4, atol=1e-7)
+    finally:
+        p.close()

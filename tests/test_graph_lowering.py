@@ -19,13 +19,36 @@ def wl(pkg):
     return importlib.import_module("paddle_lite_amd.workloads")
 
 
-def _plan(lite, wl, net, batch=2, fuse=False):
+def _plan(lite, wl, net, batch=2, fuse=False, fuse_dwpw=False):
     p = lite.Predictor(planner=True)
     try:
-        wl.emit_graph(p, net, batch, fuse=fuse)
+        wl.emit_graph(p, net, batch, fuse=fuse, fuse_dwpw=fuse_dwpw)
         return p.graph_plan()
     finally:
         p.close()
+
+
+def test_opt_in_dwpw_fusion_plan(lite, wl):
+    """GraphBuilder::set_fuse_dwpw: every depthwise_conv2d[int8_out] of MobileNetV1 has exactly one consumer, a plain 1x1
+    conv: 13 instructions disappear, the fused line carries the depthwise output scale (= the pointwise input scale) and the
+    pointwise kernel choice; MobileNetV2's project convs that carry a fused residual tail keep their own instruction."""
+    net = wl.mobilenet_v1_net()
+    base, fused = _plan(lite, wl, net, fuse=True), _plan(lite, wl, net, fuse=True, fuse_dwpw=True)
+    assert len(fused) == len(base) - 13
+    fl = [l for l in fused if "+pw=" in l]
+    assert len(fl) == 13 and all(l.startswith("depthwise_conv2d/int8_out ") for l in fl)
+    assert sum("+pw=conv2d/int8_out" in l for l in fl) == 12 and "+pw=conv2d/fp32_out via=dw14" in fl[-1]
+    W = wl.make_mobilenet_v1_weights(1234)
+    assert " out=pw2 " in fl[0] and "via=dw2" in fl[0] and "oscale=%.9g" % float(W["pw2"]["in_scale"]) in fl[0]
+    assert "pw_oscale=%.9g" % float(W["dw3"]["in_scale"]) in fl[0]
+    assert not any(l.startswith("conv2d/") and " in=dw" in l for l in fused)
+    # default stays off
+    assert not any("+pw=" in l for l in base)
+    v2 = wl.mobilenet_v2_net(res=64)
+    b2, f2 = _plan(lite, wl, v2, fuse=True), _plan(lite, wl, v2, fuse=True, fuse_dwpw=True)
+    # a project conv that carries a fused tail (residual add and / or the calib copy for the next block) is not taken over
+    plain = sum(1 for l in b2 if l.startswith("conv2d/") and l.split(" out=")[0].endswith("_dw") and "+add=" not in l and "+calib=" not in l)
+    assert 1 <= plain < 17 and sum("+pw=" in l for l in f2) == plain and len(f2) == len(b2) - plain
 
 
 def test_mobilenet_v1_graph_mode_arrives_at_appendix_d(lite, wl):
