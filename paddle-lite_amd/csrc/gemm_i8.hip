@@ -989,6 +989,13 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
   // the first-generation ring kernel at batch 128 and loses at batch 256 (both are bound by the
   // ~21 B/clk a CU ingests through LDS-DMA and by the non-overlapped epilogue, not by the K loop's instruction mix).
   // It moves END-aligned 16-byte pieces and must know the TRUE row length of a dense slab (HW = 49).
+  // Third generation (gemm_wide_i8.hip): plain 1x1 GEMMs with M >= 256 and K in {128, 256, 512, 1024}: one 256 x (128..256)
+  // tile per CU, the weight panel read once per CU, every operand byte in flight before the first MFMA.
+  if (g.im_kw == 0 && gemm_variant() == 0 && (dbg_env & ~32) == 0) {
+    GemmArgs t = g;
+    if (t.XP > 0 && t.XP < t.HWX) t.HWX = t.XP;  // the TRUE row length of a dense slab
+    if (launch_gemm_wide(t, out, s)) return;
+  }
   if (g.M > 32 && (g.im_kw > 0 || (gemm_variant() == 0 && gemm_tr_enabled() >= 2)) && (dbg_env & ~96) == 0) {
     GemmArgs t = g;
     if (t.im_kw == 0 && t.XP > 0 && t.XP < t.HWX) t.HWX = t.XP;

@@ -1,0 +1,454 @@
+// gemm_wide_i8.hip — the 1x1-convolution GEMM, third generation: ONE wide tile per CU, every operand byte in flight at once.
+//
+// Replaces the same reference code as gemm_i8.hip / gemm_tr_i8.hip (gemm_prepack_int8, lite/backends/arm/math/
+// gemm_prepacked_int8.cc:2582-2744 hot loop, :643-796 epilogue; packb_int8 :3285; the batch loop of conv1x1s1_gemm_int8,
+// conv_impl.cc:260-331) for the layers whose GEMM is SMALL per CU: MobileNetV1's 14x14 and 7x7 pointwise convs
+// (512 -> 512: 50 k outputs x K 512 per CU at batch 128).
+//
+// Why a third kernel (round-2 evidence, profiles/r02_final_gemm_timeline_pw8.txt + tools/ingest_bench.hip, round 3):
+//   * the ring kernels keep 3-4 K-steps (48-64 KB per CU) in flight and re-fetch the weight panel once per 128-column
+//     tile: 430 KB of operand ingest per CU for the 512 -> 512 layer, taken in at ~21 B/clk;
+//   * that rate is NOT what a CU can take in: LDS-DMA and register loads of 1-KiB pieces run at 56-59 B/clk/CU from L2
+//     (tools/ingest_bench.hip); a K-step takes ~1000 cycles because the next one's bytes are still travelling
+//     (64 KB in flight / 21 B/clk = 3000 cycles of loaded latency), and prologue, K loop and epilogue of the 424 short
+//     blocks add up instead of overlapping.
+// Here a block owns a 256 (m) x 32*NTT (n) tile = the whole share of one CU (1 block per CU, 8 waves), so
+//   * the weight panel is read ONCE per CU: wave w loads ITS 32 rows x K straight into registers (fragment order, as
+//     pack_weights_kernel wrote them: 1 KiB contiguous per load, the fastest form there is), K <= 1024;
+//   * the activation tile (K x 32*NTT bytes, <= 128 KiB) is LDS-resident for the whole K loop: every DMA piece has its own
+//     slot, so ALL loads of the tile are issued before the first MFMA (no ring, no slot reuse, no issue inside the loop)
+//     and a K-step only waits for bytes that were requested K-steps * 2 instructions ago;
+//   * operand reads as in gemm_tr_i8.hip: ds_read_b64_tr_b8 on the raw NCHW rows (no VALU in the K loop), activations
+//     are the A operand, so a lane owns ONE output channel and 16 consecutive columns per 32 x 32 tile after two
+//     v_permlane32_swap; the int8 tile leaves through a wave-private LDS image as 16-byte pieces of whole rows.
+// LDS image of one K-step: [group of 8 chunks (128 columns)][kg = k/8][row q = k%8][slot s][16 B], chunk j = s ^ 2(q>>1).
+// One DMA instruction = one (group, kg): 8 lanes walk 128 contiguous bytes of ONE k row (consecutive lanes on different
+// rows measured 2-4x slower from L2, tools/ingest_bench.hip rows128T); the XOR keeps the transposed read conflict-free
+// (a half-wave reads chunk pair (2t, 2t+1) of rows 0..7: slots 2((t&3) ^ (q>>1)) + parity, 16 distinct 16-byte bank slots).
+// Column space, end-aligned last 16-byte chunk of an image, `skip`: as in gemm_i8_dma_kernel (gemm_i8.hip).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "plhip_device.h"
+#include "plhip_kernels.h"
+#include "gemm_tr_common.h"
+#include "dw_common.h"
+
+namespace plhip {
+
+// ---- diagnostic timeline (PLHIP_GEMM_DEBUG & 32; never set in production) ----
+constexpr int WIDE_STAMP_SLOTS = 48;  // 0-9 phases, 10 + ks: top of K-step ks (behind its barrier)
+__device__ unsigned long long g_wide_stamps[512 * 8 * WIDE_STAMP_SLOTS];
+#define PLHIP_WIDE_STAMP(i)                                                \
+  do {                                                                     \
+    if (diag && lane == 0) lstamp[i] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+
+// NTT 32-column n tiles per block (4..8), KS K-steps of 32 (K = 32 KS exactly); A0 K-steps are issued before the loop and R
+// more behind the barrier of every K-step until all KS are in flight (issuing everything first cost 4.4 k cycles in front of
+// the first MFMA: 240 KB per CU at the ~58 B/clk the address path takes in)
+template <int NTT, int KS, int OUT, int A0, int R>
+__global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
+  constexpr int G = (NTT + 3) / 4;   // groups of 8 chunks = DMA pieces per kg
+  constexpr int NCH = 2 * NTT;       // 16-column chunks per tile
+  constexpr int KSTEP = G * 4096;    // LDS bytes of one K-step
+  constexpr int PITCH = NTT * 32 + 16;  // int8 staging row pitch (odd multiple of 16: conflict-free 16-byte row writes)
+  static_assert(NTT >= 1 && NTT <= 8 && A0 >= 2 && A0 <= KS && R >= 1, "tile");
+  constexpr auto issued_before = [](int ks) { return A0 + R * ks < KS ? A0 + R * ks : KS; };  // K-steps issued when step ks starts
+  PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.x); PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias);
+  PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP); PLHIP_PRELOAD(g.NB);
+  PLHIP_PRELOAD(g.x_bstride); PLHIP_PRELOAD(g.y_bstride); PLHIP_PRELOAD(g.MT); PLHIP_PRELOAD(g.NT);
+  PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg); PLHIP_PRELOAD(g.cpi_m); PLHIP_PRELOAD(g.cpi_s);
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // KS * KSTEP bytes (then the staging images)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int mb, nb;
+  tr_xcd_tile_map(blockIdx.x, g.MT, g.NT, mb, nb);  // g.MT / g.NT = blocks along M / N (launcher)
+  if (nb >= g.NT) return;                            // block-uniform (grid padded to 8 N blocks)
+  const int c = lane & 31, h = lane >> 5;
+  const bool diag = (g.dbg & 32) != 0;
+  constexpr int LDS_MAIN = KS * KSTEP > 8 * 32 * PITCH ? KS * KSTEP : 8 * 32 * PITCH;
+  unsigned long long* lstamp = reinterpret_cast<unsigned long long*>(ring + LDS_MAIN) + wave * WIDE_STAMP_SLOTS;
+  if (diag && lane == 0) {
+    lstamp[0] = __builtin_amdgcn_s_memrealtime();
+    lstamp[1] = __builtin_amdgcn_s_memtime();
+    lstamp[2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  }
+
+  // ---- column space: every image's HWX columns padded to HWP = roundup(HWX, 16); the last chunk of an image is
+  // END-aligned (source columns HWX-16 .. HWX-1), its leading 16 - HWX%16 columns are duplicates that are never stored
+  const int HWP = (g.HWX + 15) & ~15, full16 = g.HWX & ~15, rem16 = g.HWX & 15;
+  const int CPI = HWP >> 4;  // chunks per image
+
+  // ---- this lane's scale / bias: ordinary loads, first and alone; consumed after the K loop
+  const int mt = mb * 8 + wave;  // my 32-row m tile (wave-uniform)
+  const int mrow = mt * 32 + c;
+  float sc = 1.f, bi = 0.f;
+  if (OUT != OUT_I32 && mrow < g.M) {
+    sc = g.scale[mrow];
+    if (g.bias) bi = g.bias[mrow];
+  }
+
+  // ---- my DMA piece of every K-step: (group grp, kg) [G == 2], or half of (0, kg) [G == 1: rows 4 half .. +3, 32 lanes]
+  const int kg = wave >> 1;
+  const int grp = G == 2 ? (wave & 1) : 0;
+  const int q = (G == 2 ? 0 : (wave & 1) * 4) + (lane >> 3);  // k row inside the 8-row group (G == 1: lanes < 32 only)
+  const bool dma_lane = G == 2 || lane < 32;
+  int ch = grp * 8 + ((lane & 7) ^ (2 * ((q & 7) >> 1)));  // my 16-column chunk of the tile
+  if (ch >= NCH) ch -= 2;  // NTT = 5..7: the last group's spare slots re-fetch a neighbour (same cache line; never read)
+  const uint8_t* asrc;
+  {
+    const uint32_t J = (uint32_t)nb * NCH + ch;
+    uint32_t pb = fastdiv_u31(J, g.cpi_m, g.cpi_s);
+    int pj = (int)(J - pb * CPI) << 4;
+    if (pb >= (uint32_t)g.NB) { pb = 0; pj = 0; }  // past the last image: any legal bytes (their columns are never stored)
+    const int pcol = pj < full16 ? pj : g.HWX - 16;
+    asrc = reinterpret_cast<const uint8_t*>(g.x) + (size_t)pb * g.x_bstride + (size_t)(kg * 8 + (q & 7)) * (uint32_t)g.XP + pcol;
+  }
+  const size_t astep = (size_t)32 * (uint32_t)g.XP;
+  const int a_ldsoff = grp * 4096 + kg * 1024 + (G == 2 ? 0 : (wave & 1) * 512);  // wave-uniform
+  // ---- my weight fragments: [mt][ks][64 lanes][16 B]; tiles past M: any packed tile (their rows are never stored)
+  const int MT32 = (g.M + 31) >> 5;
+  const uint8_t* wbase = reinterpret_cast<const uint8_t*>(g.wp) + (size_t)(mt < MT32 ? mt : MT32 - 1) * (KS * 1024);  // wave-uniform
+  const uint32_t wlane = lane * 16;
+
+  v4i w[KS];
+  auto issue = [&](int ks) __attribute__((always_inline)) {
+    // weights: inline asm (next to LDS-DMA the compiler guards ordinary loads with vmcnt(0)); the counted waits below
+    // order them.  Obligation: no register copy of an in-flight fragment (tools/check_wide_isa.py).
+    const uint32_t vo = wlane + (uint32_t)(ks >> 2) * 4096u;
+    switch (ks & 3) {
+      case 0: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[ks]) : "v"(vo), "s"(wbase) : "memory"); break;
+      case 1: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w[ks]) : "v"(vo), "s"(wbase) : "memory"); break;
+      case 2: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(w[ks]) : "v"(vo), "s"(wbase) : "memory"); break;
+      default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(w[ks]) : "v"(vo), "s"(wbase) : "memory"); break;
+    }
+    if (dma_lane)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc + (size_t)ks * astep), (lds_ptr_t)(ring + ks * KSTEP + a_ldsoff), 16, 0, 0);
+  };
+#pragma unroll
+  for (int ks = 0; ks < A0; ++ks) issue(ks);
+  PLHIP_WIDE_STAMP(3);
+
+  // ---- transposed-read addresses: tile t <-> chunk pair (2t, 2t+1) of group t>>2; lane 2q'+p of a 16-lane group -> row
+  // q', sub-chunk p; 16-lane group parity -> chunk parity; k half h -> kg {2h, 2h+1}
+  const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring;
+  uint32_t tr_addr[4];
+  {
+    const int qr = (lane & 15) >> 1, par = (lane >> 4) & 1;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+      tr_addr[tt] = ring_addr + (h * 2) * 1024 + qr * 128 + ((2 * (tt ^ (qr >> 1)) + par) * 16) + (lane & 1) * 8;
+  }
+  v2i lo[NTT], hi[NTT];
+
+  v16i acc[NTT];
+#pragma unroll
+  for (int t = 0; t < NTT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+
+  // The K loop is written out through a recursive template-free unroll: every offset and wait count is a constant.
+#define PLHIP_WIDE_READ(KS_, T_)                                                                                               \
+  do {                                                                                                                          \
+    constexpr int off_ = (KS_) * KSTEP + ((T_) >> 2) * 4096;                                                                    \
+    const uint32_t a_ = tr_addr[(T_) & 3] + (uint32_t)(off_ & ~0xffff);                                                         \
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(lo[T_]) : "v"(a_), "n"(off_ & 0xffff) : "memory");                 \
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(hi[T_]) : "v"(a_), "n"((off_ & 0xffff) + 1024) : "memory");        \
+  } while (0)
+
+  // step -1: K-step 0 has landed everywhere; read its fragments
+  {
+    constexpr int younger = 2 * (A0 - 1);
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(younger) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  PLHIP_WIDE_STAMP(4);
+  auto kloop = [&](auto self, auto ks_c) __attribute__((always_inline)) -> void {
+    constexpr int ks = decltype(ks_c)::value;
+    if constexpr (ks == 0) {
+      // fragments of K-step 0
+      auto rd = [&](auto rself, auto t_c) __attribute__((always_inline)) -> void {
+        constexpr int t = decltype(t_c)::value;
+        if constexpr (t < NTT) {
+          PLHIP_WIDE_READ(0, t);
+          rself(rself, std::integral_constant<int, t + 1>{});
+        }
+      };
+      rd(rd, std::integral_constant<int, 0>{});
+    }
+    if constexpr (ks < KS) {
+      constexpr bool NEXT = ks + 1 < KS;
+      if constexpr (NEXT) {
+        // K-step ks+1 has landed: my loads of it are done (everything issued behind them may still fly), then everyone's
+        constexpr int younger = 2 * (issued_before(ks) - (ks + 2));
+        static_assert(younger >= 0 && 2 * (issued_before(ks + 1) - ks) <= 60, "vmcnt range");
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[ks + 1]) : "n"(younger) : "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = issued_before(ks); i < issued_before(ks + 1); ++i) issue(i);
+      }
+      PLHIP_WIDE_STAMP(10 + ks);
+      auto mm = [&](auto mself, auto t_c) __attribute__((always_inline)) -> void {
+        constexpr int t = decltype(t_c)::value;
+        if constexpr (t < NTT) {
+          // fragment t of this K-step: reads issued behind it = tiles t+1.. of this step and 0..t-1 of the next
+          constexpr int yl = NEXT ? 2 * (NTT - 1) : 2 * (NTT - 1 - t);
+          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo[t]), "+v"(hi[t]) : "n"(yl) : "memory");
+          const v4i a = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w[ks], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);  // the MFMA stays between its fragment's wait and the next read (the scheduler sank all of them below three K-steps of reads)
+          if constexpr (NEXT) PLHIP_WIDE_READ(ks + 1, t);
+          __builtin_amdgcn_sched_barrier(0);
+          mself(mself, std::integral_constant<int, t + 1>{});
+        }
+      };
+      mm(mm, std::integral_constant<int, 0>{});
+      self(self, std::integral_constant<int, ks + 1>{});
+    }
+  };
+  kloop(kloop, std::integral_constant<int, 0>{});
+#undef PLHIP_WIDE_READ
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PLHIP_WIDE_STAMP(5);
+
+  // ---- epilogue: lane (c, h) owns channel row mrow; per n tile t, register r <-> n = 32t + 8(r>>2) + 4h + (r&3)
+  if (OUT == OUT_I8) {
+    __builtin_amdgcn_s_barrier();  // every wave has finished reading the activation tile: it becomes staging space
+    uint8_t* stg = ring + wave * (32 * PITCH);
+    const float hi2 = g.act == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
+    const float lo2 = (g.act == ACT_RELU || g.act == ACT_RELU6) ? 0.f : -254.f;
+    const float s2 = sc + sc, b2 = bi + bi;
+#define PLHIP_WIDE_STAGE(ACT_)                                                                                      \
+  _Pragma("unroll") for (int t = 0; t < NTT; ++t)                                                                   \
+      *reinterpret_cast<v4i*>(stg + c * PITCH + (2 * t + h) * 16) = tr_requant_chunk<ACT_>(acc[t], s2, b2, g.alpha, lo2, hi2)
+    switch (g.act) {  // wave-uniform: straight-line requantisation per activation
+      case ACT_RELU: PLHIP_WIDE_STAGE(ACT_RELU); break;
+      case ACT_RELU6: PLHIP_WIDE_STAGE(ACT_RELU6); break;
+      case ACT_LEAKY: PLHIP_WIDE_STAGE(ACT_LEAKY); break;
+      default: PLHIP_WIDE_STAGE(ACT_NONE); break;
+    }
+#undef PLHIP_WIDE_STAGE
+    PLHIP_WIDE_STAMP(6);
+    // store: a lane keeps ONE 16-column chunk for all rounds; LPR lanes walk a row
+    constexpr int LPR = NCH <= 8 ? 8 : 16, RPI = 64 / LPR;
+    const int r0 = lane / LPR, cj = lane % LPR;
+    const uint32_t J = (uint32_t)nb * NCH + (cj < NCH ? cj : 0);
+    const uint32_t b = fastdiv_u31(J, g.cpi_m, g.cpi_s);
+    const int pj = (int)(J - b * CPI) << 4;
+    const bool cvalid = cj < NCH && b < (uint32_t)g.NB;
+    const int hw0 = pj < full16 ? pj : g.HWX - 16;
+    const int skip = pj < full16 ? 0 : 16 - rem16;
+    const int room = g.HWY - hw0;
+    const int m0 = mt * 32 + r0;
+    int8_t* yp = reinterpret_cast<int8_t*>(g.y) + (size_t)b * g.y_bstride + (size_t)m0 * (uint32_t)g.HWY + hw0;
+    const uint8_t* rp = stg + r0 * PITCH + cj * 16;
+    // full chunks leave as one 16-byte store; the END-aligned last chunk of an image holds rem16 new bytes (its first
+    // `skip` are duplicates of the previous chunk): 8 + 4 + 2 + 1-byte pieces picked by the bits of rem16 (kernel-uniform;
+    // 14x14: one dword, 7x7: one byte).  (store_chunk_i8's per-dword / per-byte cascade here cost 5 k cycles per block.)
+    const bool tail = skip != 0;
+    (void)room;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const v4i v = *reinterpret_cast<const v4i*>(rp + i * RPI * PITCH);
+      const bool ok = cvalid && m0 + RPI * i < g.M;
+      int8_t* qd = yp + (size_t)(RPI * i) * (uint32_t)g.HWY;
+      if (ok && !tail) __builtin_memcpy(qd, &v, 16);  // possibly unaligned: fine for global memory
+      if (rem16 != 0 && ok && tail) {
+        const uint64_t w0 = (uint32_t)v[0] | ((uint64_t)(uint32_t)v[1] << 32), w1 = (uint32_t)v[2] | ((uint64_t)(uint32_t)v[3] << 32);
+        const int sh = 8 * (skip & 7);  // kernel-uniform
+        uint64_t t0, t1;
+        if (skip >= 8) {
+          t0 = w1 >> sh;
+          t1 = 0;
+        } else {
+          t0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+          t1 = w1 >> sh;
+        }
+        int8_t* pd = qd + skip;
+        if (rem16 & 8) { __builtin_memcpy(pd, &t0, 8); pd += 8; t0 = t1; }
+        if (rem16 & 4) { const uint32_t d4 = (uint32_t)t0; __builtin_memcpy(pd, &d4, 4); pd += 4; t0 >>= 32; }
+        if (rem16 & 2) { const uint16_t d2 = (uint16_t)t0; __builtin_memcpy(pd, &d2, 2); pd += 2; t0 >>= 16; }
+        if (rem16 & 1) *pd = (int8_t)t0;
+      }
+    }
+  } else {
+    // 32-bit outputs: a lane's 4 consecutive n of register group gq are one 16-byte store; chunk 2t + (gq >> 1),
+    // column 8 (gq & 1) + 4h inside it
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+#pragma unroll
+      for (int jc = 0; jc < 2; ++jc) {
+        const uint32_t J = (uint32_t)nb * NCH + 2 * t + jc;
+        const uint32_t b = fastdiv_u31(J, g.cpi_m, g.cpi_s);
+        const int pj = (int)(J - b * CPI) << 4;
+        const bool cvalid = b < (uint32_t)g.NB && mrow < g.M;
+        const int hw0 = pj < full16 ? pj : g.HWX - 16;
+        const int skip = pj < full16 ? 0 : 16 - rem16;
+        const int room = g.HWY - hw0;
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl) {
+          const int gq = 2 * jc + gl;
+          const int o = 8 * gl + 4 * h;  // first column of the group inside the chunk
+          if (!cvalid || o + 3 < skip || o >= room) continue;
+          const size_t yoff = (size_t)b * g.y_bstride + (size_t)mrow * (uint32_t)g.HWY + hw0 + o;
+          const bool whole = o >= skip && o + 3 < room;
+          if (OUT == OUT_I32) {
+            int* yp = reinterpret_cast<int*>(g.y) + yoff;
+            if (whole) {
+              const v4i v = {acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]};
+              __builtin_memcpy(yp, &v, 16);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (o + e >= skip && o + e < room) yp[e] = acc[t][4 * gq + e];
+            }
+          } else {
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = epilogue_f32(acc[t][4 * gq + e], sc, bi, g.act, g.alpha);
+            float* yp = reinterpret_cast<float*>(g.y) + yoff;
+            if (whole) {
+              const v4f v = {f[0], f[1], f[2], f[3]};
+              __builtin_memcpy(yp, &v, 16);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (o + e >= skip && o + e < room) yp[e] = f[e];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (diag) {  // wave-uniform
+    PLHIP_WIDE_STAMP(7);  // epilogue instructions issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      lstamp[8] = __builtin_amdgcn_s_memtime();  // stores acknowledged
+      lstamp[9] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (blockIdx.x < 512 && lane < WIDE_STAMP_SLOTS)
+      g_wide_stamps[((size_t)blockIdx.x * 8 + wave) * WIDE_STAMP_SLOTS + lane] = lstamp[lane];
+  }
+}
+
+int debug_read_wide_stamps(void* dst, size_t bytes) {
+  const size_t cap = sizeof(unsigned long long) * 512 * 8 * WIDE_STAMP_SLOTS;
+  if (bytes > cap) bytes = cap;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wide_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+
+static int g_wide_ntt_override = -1;  // tests / A-B runs: plhip_debug_wide_ntt (-1 = PLHIP_WIDE_NTT or automatic)
+void debug_set_wide_ntt(int v) { g_wide_ntt_override = v; }
+
+static int wide_env() {  // PLHIP_GEMM_WIDE: 1 (default) on, 0 = second-generation kernels only (A/B runs)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PLHIP_GEMM_WIDE");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+static void cpi_magic(long d, unsigned& m, int& sh) {  // fastdiv_u31's (magic, shift) for divisor d (dw_common.h)
+  int l = 0;
+  while ((1L << l) < d) ++l;
+  if ((1L << l) == d) {
+    m = 0;
+    sh = l;
+    return;
+  }
+  m = (unsigned)(((1ULL << (31 + l)) / (unsigned long long)d) + 1ULL);
+  sh = l - 1;
+}
+
+template <int NTT, int KS, int OUT>
+static void launch_wide_t(GemmArgs g, hipStream_t s) {
+  constexpr int A0 = 4, R = 2;
+  constexpr int G = (NTT + 3) / 4, KSTEP = G * 4096, PITCH = NTT * 32 + 16;
+  constexpr int LDS_MAIN = KS * KSTEP > 8 * 32 * PITCH ? KS * KSTEP : 8 * 32 * PITCH;
+  const int CPI = (g.HWX + 15) >> 4;
+  const long chunks = (long)g.NB * CPI;
+  g.NT = (int)((chunks + 2 * NTT - 1) / (2 * NTT));
+  g.MT = (g.M + 255) / 256;
+  cpi_magic(CPI, g.cpi_m, g.cpi_s);
+  const unsigned blocks = (unsigned)((long)g.MT * ((g.NT + 7) / 8 * 8));
+  const size_t lds = (size_t)LDS_MAIN + 8 * WIDE_STAMP_SLOTS * 8;
+  auto kfn = gemm_i8_wide_kernel<NTT, KS, OUT, A0, R>;
+  (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, g);
+}
+
+template <int NTT, int KS>
+static void launch_wide_o(const GemmArgs& g, int out, hipStream_t s) {
+  if (out == OUT_I32) launch_wide_t<NTT, KS, OUT_I32>(g, s);
+  else if (out == OUT_F32) launch_wide_t<NTT, KS, OUT_F32>(g, s);
+  else launch_wide_t<NTT, KS, OUT_I8>(g, s);
+}
+
+// The tile of a launch: n tiles per block so that the blocks fill the CUs once with as little idle tail as possible.
+// Returns 0 when the shape is outside this kernel (the caller falls back to the ring kernels).
+int gemm_wide_ntt(const GemmArgs& g) {
+  if (!wide_env() || g.im_kw != 0 || g.res || g.y2) return 0;
+  if (g.K != g.KS * 32 || (g.KS != 4 && g.KS != 8 && g.KS != 16 && g.KS != 32)) return 0;
+  if (g.M < 256 || g.HWX < 16) return 0;
+  const int CPI = (g.HWX + 15) >> 4;
+  const long chunks = (long)g.NB * CPI;
+  if (chunks * 16 >= ((long)1 << 31) - 4096) return 0;
+  static int force_env = -1;
+  if (force_env < 0) {
+    const char* e = getenv("PLHIP_WIDE_NTT");
+    force_env = e ? atoi(e) : 0;
+  }
+  const int force = g_wide_ntt_override >= 0 ? g_wide_ntt_override : force_env;
+  const int mblocks = (g.M + 255) / 256;
+  int best = 0;
+  double best_cost = 1e30;
+  const int cands[3] = {4, 7, 8};
+  for (int i = 0; i < 3; ++i) {
+    const int ntt = cands[i];
+    if (force && ntt != force) continue;
+    if ((long)g.KS * ((ntt + 3) / 4) * 4096 > 144 * 1024) continue;  // the activation tile must fit the LDS
+    const long nblocks = (chunks + 2 * ntt - 1) / (2 * ntt);
+    const long blocks = nblocks * mblocks;
+    const long rounds = (blocks + 255) / 256;
+    // time ~ rounds x (operand ingest of a tile + a fixed prologue / epilogue share)
+    const double cost = (double)rounds * ((double)g.KS * 32 * (256 + 32 * ntt) + 40000.0);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = ntt;
+    }
+  }
+  return best;
+}
+
+bool launch_gemm_wide(const GemmArgs& g_in, int out, hipStream_t s) {
+  const int ntt = gemm_wide_ntt(g_in);
+  if (!ntt) return false;
+  GemmArgs g = g_in;
+#define PLHIP_WIDE_KS(NTT_)                                   \
+  do {                                                        \
+    if (g.KS == 4) launch_wide_o<NTT_, 4>(g, out, s);         \
+    else if (g.KS == 8) launch_wide_o<NTT_, 8>(g, out, s);    \
+    else if (g.KS == 16) launch_wide_o<NTT_, 16>(g, out, s);  \
+    else launch_wide_o<NTT_, 32>(g, out, s);                  \
+  } while (0)
+  if (ntt == 4) PLHIP_WIDE_KS(4);
+  else if (ntt == 7) {
+    if (g.KS == 32) return false;
+    if (g.KS == 4) launch_wide_o<7, 4>(g, out, s);
+    else if (g.KS == 8) launch_wide_o<7, 8>(g, out, s);
+    else launch_wide_o<7, 16>(g, out, s);
+  } else {
+    if (g.KS == 32) return false;
+    if (g.KS == 4) launch_wide_o<8, 4>(g, out, s);
+    else if (g.KS == 8) launch_wide_o<8, 8>(g, out, s);
+    else launch_wide_o<8, 16>(g, out, s);
+  }
+#undef PLHIP_WIDE_KS
+  return true;
+}
+
+}  // namespace plhip

@@ -774,6 +774,12 @@ int debug_read_stamps(void* dst, size_t bytes);
 int debug_read_tr_stamps(void* dst, size_t bytes);
 int debug_read_fz_stamps(void* dst, size_t bytes);
 }
+extern "C" int plhip_debug_read_wide_stamps(void* dst_host, size_t bytes) {
+  if (!dst_host) return -1;
+  return plhip::debug_read_wide_stamps(dst_host, bytes);
+}
+// tests / A-B runs: force the wide-tile GEMM's n tiles per block (4, 7, 8), 0 = automatic choice, -1 = environment
+extern "C" void plhip_debug_wide_ntt(int v) { plhip::debug_set_wide_ntt(v); }
 extern "C" int plhip_debug_read_tr_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();
   return plhip::debug_read_tr_stamps(dst_host, bytes);

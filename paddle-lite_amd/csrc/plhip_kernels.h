@@ -39,6 +39,9 @@ struct GemmArgs {
   // (c, p, q) holds padded[c][2y + p][2x + q] (im_ph x im_pw each), so that tap (r, s) of output (oh, ow) is byte
   // ((c*4 + (r&1)*2 + (s&1)) * im_ph + oh + (r>>1)) * im_pw + ow + (s>>1): contiguous in ow again.
   int im_s;
+  // wide-tile kernel (gemm_wide_i8.hip): fastdiv_u31's (magic, shift) for the chunks per image, set by its launcher
+  unsigned cpi_m;
+  int cpi_s;
 };
 
 struct PadArgs {
@@ -111,6 +114,11 @@ void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool ali
 // second-generation ring kernel (gemm_tr_i8.hip); false = shape outside it, the caller falls back
 bool launch_gemm_tr(const GemmArgs& g, int out, hipStream_t s);
 int gemm_tr_enabled();
+// third-generation kernel: one wide tile per CU (gemm_wide_i8.hip); false = shape outside it, the caller falls back
+bool launch_gemm_wide(const GemmArgs& g, int out, hipStream_t s);
+int gemm_wide_ntt(const GemmArgs& g);  // n tiles per block it would use, 0 = not taken
+int debug_read_wide_stamps(void* dst, size_t bytes);
+void debug_set_wide_ntt(int v);  // 4 / 7 / 8 force that tile, 0 = automatic, -1 = back to the environment's choice
 void launch_pack_weights(const int8_t* w, int8_t* wp, int G, int Mg, int Kg, int MT32, int KS, hipStream_t s);
 void launch_im2col(const Im2colArgs& a, hipStream_t s);
 int launch_depthwise(const DwArgs& a, int out, hipStream_t s);  // returns 0 or -3 (unsupported LDS size)

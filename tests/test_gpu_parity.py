@@ -221,6 +221,35 @@ def test_ring_gemm_column_space(gpu_ctx, pkg, plref):
     assert cnt == 32
 
 
+def test_wide_gemm_tiles(gpu_ctx, pkg, plref):
+    """The wide-tile kernel (gemm_wide_i8.hip: M >= 256, K in {128, 256, 512, 1024}; one 256 x 32*NTT tile per block): every
+    tile width it can pick (plhip_debug_wide_ntt 4 / 7 / 8 and the automatic choice) over HW % 16 in {0, 1, 4, 9, 12, 14}
+    (end-aligned last chunk, skipped duplicates, byte-unaligned pieces), M tails (300, 257: m tiles past M), batches that
+    do not fill the last tile, all three output kinds and all activations."""
+    rng = np.random.default_rng(301)
+    capi = pkg.capi
+    lib = capi.load()
+    cnt = 0
+    try:
+        for ntt in (4, 7, 8, 0):
+            lib.plhip_debug_wide_ntt(ntt)
+            for (h, w) in [(4, 4), (1, 17), (14, 14), (7, 7), (5, 5), (28, 28), (3, 20)]:
+                for (cin, cout) in [(128, 256), (256, 300), (512, 512), (1024, 257)]:
+                    if ntt in (7, 8) and cin == 1024:
+                        continue  # K = 1024 only fits the LDS with 4 n tiles
+                    if (h * w > 200 and cin > 256) or (ntt == 0 and (cnt % 3)):
+                        cnt += 1
+                        continue
+                    act = (0, 1, 2, 4)[cnt % 4]
+                    n = 1 + (cnt % 5)
+                    assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 1, 1, (0, 0, 0, 0), 1, 1, 1,
+                                            act, 6.0 if act == 2 else 0.3, cnt % 2 == 0, rng) == 1
+                    cnt += 1
+    finally:
+        lib.plhip_debug_wide_ntt(-1)
+    assert cnt > 60
+
+
 def test_stem_mfma_variants(gpu_ctx, pkg, plref):
     """conv3x3s2 stem on the MFMA path (Cin <= 3, OW % 4 == 0): Cin 1/2/3, Cout tails and two M tiles, pads 0/1, more
     than 32 quads per row (two column tiles), OH % 4 != 0 (partly empty row groups), several images; plus shapes that
