@@ -45,22 +45,36 @@ __device__ unsigned long long g_wide_stamps[512 * 8 * WIDE_STAMP_SLOTS];
     if (diag && lane == 0) lstamp[i] = __builtin_amdgcn_s_memtime();       \
   } while (0)
 
-// NTT 32-column n tiles per block (4..8), KS K-steps of 32 (K = 32 KS exactly); A0 K-steps are issued before the loop and R
-// more behind the barrier of every K-step until all KS are in flight (issuing everything first cost 4.4 k cycles in front of
-// the first MFMA: 240 KB per CU at the ~58 B/clk the address path takes in)
+// NTT 32-column n tiles per block (4, 7, 8), KS K-steps of 32 (K = 32 KS exactly); A0 K-steps are issued before the loop and
+// R more inside every K-step until all KS are in flight (issuing everything first cost 4.4 k cycles in front of the first
+// MFMA: 240 KB per CU at the ~58 B/clk the address path takes in).
+//
+// Two passes over the tile's columns and two wave roles (timeline of the one-pass form, profiles/r03_wide_timeline_v1.txt:
+// K loop 10.2 k cycles with the matrix pipe 70 % busy and the VALU idle, then an epilogue of 7.5 k cycles with the matrix
+// pipe idle, both waves of a SIMD in the same phase all the time):
+//   pass 1 = n tiles [0, TS), pass 2 = [TS, NTT).  All 8 waves run the K loop of pass 1 together: it carries the counted
+//   waits and the one barrier per K-step that make the operands visible; when it ends every byte of the tile is in LDS /
+//   registers and NO barrier follows.  Then waves 0-3 (one per SIMD) requantise + store pass 1 while waves 4-7 run the K
+//   loop of pass 2 on the same SIMDs (VALU / store path beside the matrix pipe), and swap: waves 0-3 K loop 2, waves 4-7
+//   epilogue 1; both finish with epilogue 2.  Staging images are wave-private and live BEHIND the tile (other waves still
+//   read it), so the tile's LDS image is dense: group 1 of a 7-tile block has 6 chunk slots (96-byte rows: conflict-free
+//   without the XOR, 6 q mod 16 are 8 distinct even slots), filled by 48-lane DMA instructions.
 template <int NTT, int KS, int OUT, int A0, int R>
 __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
-  constexpr int G = (NTT + 3) / 4;   // groups of 8 chunks = DMA pieces per kg
-  constexpr int NCH = 2 * NTT;       // 16-column chunks per tile
-  constexpr int KSTEP = G * 4096;    // LDS bytes of one K-step
-  constexpr int PITCH = NTT * 32 + 16;  // int8 staging row pitch (odd multiple of 16: conflict-free 16-byte row writes)
-  static_assert(NTT >= 1 && NTT <= 8 && A0 >= 2 && A0 <= KS && R >= 1, "tile");
+  constexpr int NCH = 2 * NTT;                     // 16-column chunks per tile
+  constexpr int C1 = NCH > 8 ? NCH - 8 : 0;        // chunk slots of group 1 (0: one group, two waves share a DMA piece)
+  constexpr int P1 = C1 * 128;                     // bytes of a group-1 piece (group 0: 1024)
+  constexpr int KSTEP = 4 * (1024 + P1);           // LDS bytes of one K-step: [group 0: 4 kg x 1024][group 1: 4 kg x P1]
+  constexpr int TS = NTT > 4 ? 4 : (NTT + 1) / 2;  // pass 1 = tiles [0, TS), pass 2 = [TS, NTT)
+  constexpr int PITCH = TS * 32 + 16;              // staging row pitch (odd multiple of 16: conflict-free 16-byte row writes)
+  constexpr int TILE_BYTES = KS * KSTEP;
+  static_assert((C1 == 0 || C1 == 6 || C1 == 8) && NTT >= 2 && NTT <= 8 && A0 >= 2 && A0 <= KS && R >= 1 && R <= TS, "tile");
   constexpr auto issued_before = [](int ks) { return A0 + R * ks < KS ? A0 + R * ks : KS; };  // K-steps issued when step ks starts
   PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.x); PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias);
   PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP); PLHIP_PRELOAD(g.NB);
   PLHIP_PRELOAD(g.x_bstride); PLHIP_PRELOAD(g.y_bstride); PLHIP_PRELOAD(g.MT); PLHIP_PRELOAD(g.NT);
   PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.dbg); PLHIP_PRELOAD(g.cpi_m); PLHIP_PRELOAD(g.cpi_s);
-  extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // KS * KSTEP bytes (then the staging images)
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // [tile: TILE_BYTES][8 staging images][stamps]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int mb, nb;
@@ -68,8 +82,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
   if (nb >= g.NT) return;                            // block-uniform (grid padded to 8 N blocks)
   const int c = lane & 31, h = lane >> 5;
   const bool diag = (g.dbg & 32) != 0;
-  constexpr int LDS_MAIN = KS * KSTEP > 8 * 32 * PITCH ? KS * KSTEP : 8 * 32 * PITCH;
-  unsigned long long* lstamp = reinterpret_cast<unsigned long long*>(ring + LDS_MAIN) + wave * WIDE_STAMP_SLOTS;
+  unsigned long long* lstamp = reinterpret_cast<unsigned long long*>(ring + TILE_BYTES + 8 * 32 * PITCH) + wave * WIDE_STAMP_SLOTS;
   if (diag && lane == 0) {
     lstamp[0] = __builtin_amdgcn_s_memrealtime();
     lstamp[1] = __builtin_amdgcn_s_memtime();
@@ -77,8 +90,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
   }
 
   // ---- column space: every image's HWX columns padded to HWP = roundup(HWX, 16); the last chunk of an image is
-  // END-aligned (source columns HWX-16 .. HWX-1), its leading 16 - HWX%16 columns are duplicates that are never stored
-  const int HWP = (g.HWX + 15) & ~15, full16 = g.HWX & ~15, rem16 = g.HWX & 15;
+  // END-aligned (source columns HWX-16 .. HWX-1): its leading 16 - HWX%16 columns repeat the previous chunk's last ones.
+  // They are computed from the same bytes, so they come out bit-identical and the chunk is STORED whole as well.
+  const int HWP = (g.HWX + 15) & ~15, full16 = g.HWX & ~15;
   const int CPI = HWP >> 4;  // chunks per image
 
   // ---- this lane's scale / bias: ordinary loads, first and alone; consumed after the K loop
@@ -90,13 +104,29 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
     if (g.bias) bi = g.bias[mrow];
   }
 
-  // ---- my DMA piece of every K-step: (group grp, kg) [G == 2], or half of (0, kg) [G == 1: rows 4 half .. +3, 32 lanes]
+  // ---- my DMA piece of every K-step.  Two groups: wave w moves (group w & 1, kg = w >> 1); one group: waves 2 kg and
+  // 2 kg + 1 move rows 0-3 / 4-7 of piece kg (32 lanes each).  Group 0 (and an 8-slot group 1): lane -> row q = lane >> 3,
+  // slot s = lane & 7, chunk j = s ^ 2 (q >> 1).  6-slot group 1: lane < 48 -> row q = lane / 6, chunk 8 + lane % 6.
   const int kg = wave >> 1;
-  const int grp = G == 2 ? (wave & 1) : 0;
-  const int q = (G == 2 ? 0 : (wave & 1) * 4) + (lane >> 3);  // k row inside the 8-row group (G == 1: lanes < 32 only)
-  const bool dma_lane = G == 2 || lane < 32;
-  int ch = grp * 8 + ((lane & 7) ^ (2 * ((q & 7) >> 1)));  // my 16-column chunk of the tile
-  if (ch >= NCH) ch -= 2;  // NTT = 5..7: the last group's spare slots re-fetch a neighbour (same cache line; never read)
+  int q, ch, a_ldsoff;
+  bool dma_lane = true;
+  if (C1 == 0) {
+    q = (wave & 1) * 4 + (lane >> 3);
+    dma_lane = lane < 32;
+    ch = (lane & 7) ^ (2 * ((q & 7) >> 1));
+    if (ch >= NCH) ch -= 2;  // NTT < 4: spare slots re-fetch a neighbour (never read)
+    a_ldsoff = kg * 1024 + (wave & 1) * 512;
+  } else if ((wave & 1) == 0 || C1 == 8) {
+    q = lane >> 3;
+    ch = (wave & 1) * 8 + ((lane & 7) ^ (2 * (q >> 1)));
+    a_ldsoff = (wave & 1) * 4096 + kg * 1024;
+  } else {
+    q = (lane * 43) >> 8;  // lane / 6 for lane < 64
+    ch = 8 + lane - q * 6;
+    dma_lane = lane < 48;
+    a_ldsoff = 4096 + kg * P1;
+  }
+  q &= 7;
   const uint8_t* asrc;
   {
     const uint32_t J = (uint32_t)nb * NCH + ch;
@@ -104,10 +134,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
     int pj = (int)(J - pb * CPI) << 4;
     if (pb >= (uint32_t)g.NB) { pb = 0; pj = 0; }  // past the last image: any legal bytes (their columns are never stored)
     const int pcol = pj < full16 ? pj : g.HWX - 16;
-    asrc = reinterpret_cast<const uint8_t*>(g.x) + (size_t)pb * g.x_bstride + (size_t)(kg * 8 + (q & 7)) * (uint32_t)g.XP + pcol;
+    asrc = reinterpret_cast<const uint8_t*>(g.x) + (size_t)pb * g.x_bstride + (size_t)(kg * 8 + q) * (uint32_t)g.XP + pcol;
   }
   const size_t astep = (size_t)32 * (uint32_t)g.XP;
-  const int a_ldsoff = grp * 4096 + kg * 1024 + (G == 2 ? 0 : (wave & 1) * 512);  // wave-uniform
   // ---- my weight fragments: [mt][ks][64 lanes][16 B]; tiles past M: any packed tile (their rows are never stored)
   const int MT32 = (g.M + 31) >> 5;
   const uint8_t* wbase = reinterpret_cast<const uint8_t*>(g.wp) + (size_t)(mt < MT32 ? mt : MT32 - 1) * (KS * 1024);  // wave-uniform
@@ -131,199 +160,173 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
   for (int ks = 0; ks < A0; ++ks) issue(ks);
   PLHIP_WIDE_STAMP(3);
 
-  // ---- transposed-read addresses: tile t <-> chunk pair (2t, 2t+1) of group t>>2; lane 2q'+p of a 16-lane group -> row
-  // q', sub-chunk p; 16-lane group parity -> chunk parity; k half h -> kg {2h, 2h+1}
+  // ---- transposed-read addresses: tile t <-> chunk pair (2t, 2t+1); lane 2q'+p of a 16-lane group -> row q', sub-chunk
+  // p; 16-lane group parity -> chunk parity; k half h -> kg {2h, 2h+1}
   const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring;
-  uint32_t tr_addr[4];
+  uint32_t tr0[4], tr1;
   {
     const int qr = (lane & 15) >> 1, par = (lane >> 4) & 1;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
-      tr_addr[tt] = ring_addr + (h * 2) * 1024 + qr * 128 + ((2 * (tt ^ (qr >> 1)) + par) * 16) + (lane & 1) * 8;
+      tr0[tt] = ring_addr + (h * 2) * 1024 + qr * 128 + ((2 * (tt ^ (qr >> 1)) + par) * 16) + (lane & 1) * 8;
+    tr1 = ring_addr + 4096 + (h * 2) * P1 + qr * 96 + par * 16 + (lane & 1) * 8;  // 6-slot group 1
   }
   v2i lo[NTT], hi[NTT];
-
   v16i acc[NTT];
 #pragma unroll
   for (int t = 0; t < NTT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0;
 
-  // The K loop is written out through a recursive template-free unroll: every offset and wait count is a constant.
-#define PLHIP_WIDE_READ(KS_, T_)                                                                                               \
-  do {                                                                                                                          \
-    constexpr int off_ = (KS_) * KSTEP + ((T_) >> 2) * 4096;                                                                    \
-    const uint32_t a_ = tr_addr[(T_) & 3] + (uint32_t)(off_ & ~0xffff);                                                         \
-    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(lo[T_]) : "v"(a_), "n"(off_ & 0xffff) : "memory");                 \
-    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(hi[T_]) : "v"(a_), "n"((off_ & 0xffff) + 1024) : "memory");        \
+  // every offset and wait count below is a constant after unrolling
+#define PLHIP_WIDE_READ(KS_, T_)                                                                                          \
+  do {                                                                                                                     \
+    constexpr bool g1_ = (T_) >= 4 && C1 == 6;                                                                             \
+    constexpr int o_lo_ = (KS_) * KSTEP + (g1_ ? ((T_) - 4) * 32 : ((T_) >= 4 ? 4096 : 0));                                \
+    constexpr int o_hi_ = o_lo_ + (g1_ ? P1 : 1024);                                                                       \
+    const uint32_t b_ = g1_ ? tr1 : tr0[(T_) & 3];                                                                         \
+    const uint32_t a_lo_ = b_ + (uint32_t)(o_lo_ & ~0xffff), a_hi_ = b_ + (uint32_t)(o_hi_ & ~0xffff);                     \
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(lo[T_]) : "v"(a_lo_), "n"(o_lo_ & 0xffff) : "memory");        \
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(hi[T_]) : "v"(a_hi_), "n"(o_hi_ & 0xffff) : "memory");        \
   } while (0)
 
-  // step -1: K-step 0 has landed everywhere; read its fragments
-  {
-    constexpr int younger = 2 * (A0 - 1);
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(younger) : "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  PLHIP_WIDE_STAMP(4);
-  auto kloop = [&](auto self, auto ks_c) __attribute__((always_inline)) -> void {
-    constexpr int ks = decltype(ks_c)::value;
-    if constexpr (ks == 0) {
-      // fragments of K-step 0
-      auto rd = [&](auto rself, auto t_c) __attribute__((always_inline)) -> void {
-        constexpr int t = decltype(t_c)::value;
-        if constexpr (t < NTT) {
-          PLHIP_WIDE_READ(0, t);
-          rself(rself, std::integral_constant<int, t + 1>{});
-        }
-      };
-      rd(rd, std::integral_constant<int, 0>{});
-    }
-    if constexpr (ks < KS) {
-      constexpr bool NEXT = ks + 1 < KS;
-      if constexpr (NEXT) {
-        // K-step ks+1 has landed: my loads of it are done (everything issued behind them may still fly), then everyone's
-        constexpr int younger = 2 * (issued_before(ks) - (ks + 2));
-        static_assert(younger >= 0 && 2 * (issued_before(ks + 1) - ks) <= 60, "vmcnt range");
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[ks + 1]) : "n"(younger) : "memory");
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = issued_before(ks); i < issued_before(ks + 1); ++i) issue(i);
+  // K loop over the n tiles [T0, T1).  SYNC: the pass that makes the operands visible (counted vmcnt + barrier per K-step,
+  // the remaining loads issued behind the first R MFMAs of a step); !SYNC: everything has landed, no wait on memory at all.
+  auto kpass = [&](auto t0_c, auto t1_c, auto sync_c) __attribute__((always_inline)) {
+    constexpr int T0 = decltype(t0_c)::value, T1 = decltype(t1_c)::value, NTP = T1 - T0;
+    constexpr bool SYNC = decltype(sync_c)::value;
+    auto kstep = [&](auto self, auto ks_c) __attribute__((always_inline)) -> void {
+      constexpr int ks = decltype(ks_c)::value;
+      if constexpr (ks == 0) {  // fragments of K-step 0
+        auto rd = [&](auto rself, auto t_c) __attribute__((always_inline)) -> void {
+          constexpr int t = decltype(t_c)::value;
+          if constexpr (t < T1) {
+            PLHIP_WIDE_READ(0, t);
+            rself(rself, std::integral_constant<int, t + 1>{});
+          }
+        };
+        rd(rd, std::integral_constant<int, T0>{});
       }
-      PLHIP_WIDE_STAMP(10 + ks);
-      auto mm = [&](auto mself, auto t_c) __attribute__((always_inline)) -> void {
-        constexpr int t = decltype(t_c)::value;
-        if constexpr (t < NTT) {
-          // fragment t of this K-step: reads issued behind it = tiles t+1.. of this step and 0..t-1 of the next
-          constexpr int yl = NEXT ? 2 * (NTT - 1) : 2 * (NTT - 1 - t);
-          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo[t]), "+v"(hi[t]) : "n"(yl) : "memory");
-          const v4i a = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
-          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w[ks], acc[t], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);  // the MFMA stays between its fragment's wait and the next read (the scheduler sank all of them below three K-steps of reads)
-          if constexpr (NEXT) PLHIP_WIDE_READ(ks + 1, t);
-          __builtin_amdgcn_sched_barrier(0);
-          mself(mself, std::integral_constant<int, t + 1>{});
+      if constexpr (ks < KS) {
+        constexpr bool NEXT = ks + 1 < KS;
+        if constexpr (NEXT && SYNC) {
+          // K-step ks+1 has landed: my loads of it are done (everything issued behind them may still fly), then everyone's
+          constexpr int younger = 2 * (issued_before(ks) - (ks + 2));
+          static_assert(younger >= 0 && 2 * (issued_before(ks + 1) - ks) <= 60, "vmcnt range");
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[ks + 1]) : "n"(younger) : "memory");
+          __builtin_amdgcn_s_barrier();
         }
-      };
-      mm(mm, std::integral_constant<int, 0>{});
-      self(self, std::integral_constant<int, ks + 1>{});
-    }
+        if constexpr (SYNC) PLHIP_WIDE_STAMP(10 + ks);
+        auto mm = [&](auto mself, auto t_c) __attribute__((always_inline)) -> void {
+          constexpr int t = decltype(t_c)::value;
+          if constexpr (t < T1) {
+            // fragment t of this K-step: reads issued behind it = tiles t+1.. of this step and T0..t-1 of the next
+            constexpr int yl = NEXT ? 2 * (NTP - 1) : 2 * (T1 - 1 - t);
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo[t]), "+v"(hi[t]) : "n"(yl) : "memory");
+            const v4i a = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w[ks], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // the MFMA stays between its fragment's wait and the next read
+            if constexpr (NEXT) PLHIP_WIDE_READ(ks + 1, t);
+            if constexpr (SYNC && NEXT && issued_before(ks) + (t - T0) < issued_before(ks + 1)) issue(issued_before(ks) + (t - T0));
+            __builtin_amdgcn_sched_barrier(0);
+            mself(mself, std::integral_constant<int, t + 1>{});
+          }
+        };
+        mm(mm, std::integral_constant<int, T0>{});
+        self(self, std::integral_constant<int, ks + 1>{});
+      }
+    };
+    kstep(kstep, std::integral_constant<int, 0>{});
   };
-  kloop(kloop, std::integral_constant<int, 0>{});
-#undef PLHIP_WIDE_READ
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PLHIP_WIDE_STAMP(5);
 
-  // ---- epilogue: lane (c, h) owns channel row mrow; per n tile t, register r <-> n = 32t + 8(r>>2) + 4h + (r&3)
-  if (OUT == OUT_I8) {
-    __builtin_amdgcn_s_barrier();  // every wave has finished reading the activation tile: it becomes staging space
-    uint8_t* stg = ring + wave * (32 * PITCH);
-    const float hi2 = g.act == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
-    const float lo2 = (g.act == ACT_RELU || g.act == ACT_RELU6) ? 0.f : -254.f;
-    const float s2 = sc + sc, b2 = bi + bi;
-#define PLHIP_WIDE_STAGE(ACT_)                                                                                      \
-  _Pragma("unroll") for (int t = 0; t < NTT; ++t)                                                                   \
-      *reinterpret_cast<v4i*>(stg + c * PITCH + (2 * t + h) * 16) = tr_requant_chunk<ACT_>(acc[t], s2, b2, g.alpha, lo2, hi2)
-    switch (g.act) {  // wave-uniform: straight-line requantisation per activation
-      case ACT_RELU: PLHIP_WIDE_STAGE(ACT_RELU); break;
-      case ACT_RELU6: PLHIP_WIDE_STAGE(ACT_RELU6); break;
-      case ACT_LEAKY: PLHIP_WIDE_STAGE(ACT_LEAKY); break;
-      default: PLHIP_WIDE_STAGE(ACT_NONE); break;
-    }
-#undef PLHIP_WIDE_STAGE
-    PLHIP_WIDE_STAMP(6);
-    // store: a lane keeps ONE 16-column chunk for all rounds; LPR lanes walk a row
-    constexpr int LPR = NCH <= 8 ? 8 : 16, RPI = 64 / LPR;
-    const int r0 = lane / LPR, cj = lane % LPR;
-    const uint32_t J = (uint32_t)nb * NCH + (cj < NCH ? cj : 0);
-    const uint32_t b = fastdiv_u31(J, g.cpi_m, g.cpi_s);
-    const int pj = (int)(J - b * CPI) << 4;
-    const bool cvalid = cj < NCH && b < (uint32_t)g.NB;
-    const int hw0 = pj < full16 ? pj : g.HWX - 16;
-    const int skip = pj < full16 ? 0 : 16 - rem16;
-    const int room = g.HWY - hw0;
-    const int m0 = mt * 32 + r0;
-    int8_t* yp = reinterpret_cast<int8_t*>(g.y) + (size_t)b * g.y_bstride + (size_t)m0 * (uint32_t)g.HWY + hw0;
-    const uint8_t* rp = stg + r0 * PITCH + cj * 16;
-    // full chunks leave as one 16-byte store; the END-aligned last chunk of an image holds rem16 new bytes (its first
-    // `skip` are duplicates of the previous chunk): 8 + 4 + 2 + 1-byte pieces picked by the bits of rem16 (kernel-uniform;
-    // 14x14: one dword, 7x7: one byte).  (store_chunk_i8's per-dword / per-byte cascade here cost 5 k cycles per block.)
-    const bool tail = skip != 0;
-    (void)room;
+  // requantise + store (int8: through this wave's staging image) the n tiles [T0, T1)
+  const float hi2 = g.act == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
+  const float lo2 = (g.act == ACT_RELU || g.act == ACT_RELU6) ? 0.f : -254.f;
+  const float s2 = sc + sc, b2 = bi + bi;
+  auto epass = [&](auto t0_c, auto t1_c) __attribute__((always_inline)) {
+    constexpr int T0 = decltype(t0_c)::value, T1 = decltype(t1_c)::value, NTP = T1 - T0;
+    if constexpr (OUT == OUT_I8) {
+      uint8_t* stg = ring + TILE_BYTES + wave * (32 * PITCH);
+      if (g.act == ACT_RELU || g.act == ACT_RELU6) {  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
-      const v4i v = *reinterpret_cast<const v4i*>(rp + i * RPI * PITCH);
-      const bool ok = cvalid && m0 + RPI * i < g.M;
-      int8_t* qd = yp + (size_t)(RPI * i) * (uint32_t)g.HWY;
-      if (ok && !tail) __builtin_memcpy(qd, &v, 16);  // possibly unaligned: fine for global memory
-      if (rem16 != 0 && ok && tail) {
-        const uint64_t w0 = (uint32_t)v[0] | ((uint64_t)(uint32_t)v[1] << 32), w1 = (uint32_t)v[2] | ((uint64_t)(uint32_t)v[3] << 32);
-        const int sh = 8 * (skip & 7);  // kernel-uniform
-        uint64_t t0, t1;
-        if (skip >= 8) {
-          t0 = w1 >> sh;
-          t1 = 0;
-        } else {
-          t0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-          t1 = w1 >> sh;
-        }
-        int8_t* pd = qd + skip;
-        if (rem16 & 8) { __builtin_memcpy(pd, &t0, 8); pd += 8; t0 = t1; }
-        if (rem16 & 4) { const uint32_t d4 = (uint32_t)t0; __builtin_memcpy(pd, &d4, 4); pd += 4; t0 >>= 32; }
-        if (rem16 & 2) { const uint16_t d2 = (uint16_t)t0; __builtin_memcpy(pd, &d2, 2); pd += 2; t0 >>= 16; }
-        if (rem16 & 1) *pd = (int8_t)t0;
+        for (int t = T0; t < T1; ++t)
+          *reinterpret_cast<v4i*>(stg + c * PITCH + (2 * (t - T0) + h) * 16) = tr_requant_chunk<ACT_RELU>(acc[t], s2, b2, g.alpha, lo2, hi2);
+      } else {  // none / leaky: one straight-line form (alpha = 1 for none)
+        const float al = g.act == ACT_LEAKY ? g.alpha : 1.f;
+#pragma unroll
+        for (int t = T0; t < T1; ++t)
+          *reinterpret_cast<v4i*>(stg + c * PITCH + (2 * (t - T0) + h) * 16) = tr_requant_chunk<ACT_LEAKY>(acc[t], s2, b2, al, lo2, hi2);
       }
-    }
-  } else {
-    // 32-bit outputs: a lane's 4 consecutive n of register group gq are one 16-byte store; chunk 2t + (gq >> 1),
-    // column 8 (gq & 1) + 4h inside it
+      // store: a lane keeps ONE 16-column chunk for all rounds; 8 lanes walk a row of <= 128 bytes
+      const int r0 = lane >> 3, cj = lane & 7;
+      const uint32_t J = (uint32_t)nb * NCH + 2 * T0 + (cj < 2 * NTP ? cj : 0);
+      const uint32_t b = fastdiv_u31(J, g.cpi_m, g.cpi_s);
+      const int pj = (int)(J - b * CPI) << 4;
+      const bool cvalid = cj < 2 * NTP && b < (uint32_t)g.NB;
+      const int hw0 = pj < full16 ? pj : g.HWX - 16;
+      const int m0 = mt * 32 + r0;
+      int8_t* yp = reinterpret_cast<int8_t*>(g.y) + (size_t)b * g.y_bstride + (size_t)m0 * (uint32_t)g.HWY + hw0;
+      const uint8_t* rp = stg + r0 * PITCH + cj * 16;
 #pragma unroll
-    for (int t = 0; t < NTT; ++t) {
+      for (int i = 0; i < 4; ++i) {
+        const v4i v = *reinterpret_cast<const v4i*>(rp + i * 8 * PITCH);
+        if (cvalid && m0 + 8 * i < g.M) __builtin_memcpy(yp + (size_t)(8 * i) * (uint32_t)g.HWY, &v, 16);  // possibly unaligned: fine
+      }
+    } else {
+      // 32-bit outputs: a lane's 4 consecutive n of register group gq are one 16-byte store; chunk 2t + (gq >> 1),
+      // column 8 (gq & 1) + 4h inside it.  The duplicate columns of an end-aligned chunk are rewritten with equal values.
 #pragma unroll
-      for (int jc = 0; jc < 2; ++jc) {
-        const uint32_t J = (uint32_t)nb * NCH + 2 * t + jc;
-        const uint32_t b = fastdiv_u31(J, g.cpi_m, g.cpi_s);
-        const int pj = (int)(J - b * CPI) << 4;
-        const bool cvalid = b < (uint32_t)g.NB && mrow < g.M;
-        const int hw0 = pj < full16 ? pj : g.HWX - 16;
-        const int skip = pj < full16 ? 0 : 16 - rem16;
-        const int room = g.HWY - hw0;
+      for (int t = T0; t < T1; ++t) {
 #pragma unroll
-        for (int gl = 0; gl < 2; ++gl) {
-          const int gq = 2 * jc + gl;
-          const int o = 8 * gl + 4 * h;  // first column of the group inside the chunk
-          if (!cvalid || o + 3 < skip || o >= room) continue;
-          const size_t yoff = (size_t)b * g.y_bstride + (size_t)mrow * (uint32_t)g.HWY + hw0 + o;
-          const bool whole = o >= skip && o + 3 < room;
-          if (OUT == OUT_I32) {
-            int* yp = reinterpret_cast<int*>(g.y) + yoff;
-            if (whole) {
+        for (int jc = 0; jc < 2; ++jc) {
+          const uint32_t J = (uint32_t)nb * NCH + 2 * t + jc;
+          const uint32_t b = fastdiv_u31(J, g.cpi_m, g.cpi_s);
+          const int pj = (int)(J - b * CPI) << 4;
+          if (b >= (uint32_t)g.NB || mrow >= g.M) continue;
+          const int hw0 = pj < full16 ? pj : g.HWX - 16;
+#pragma unroll
+          for (int gl = 0; gl < 2; ++gl) {
+            const int gq = 2 * jc + gl;
+            const size_t yoff = (size_t)b * g.y_bstride + (size_t)mrow * (uint32_t)g.HWY + hw0 + 8 * gl + 4 * h;
+            if (OUT == OUT_I32) {
               const v4i v = {acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]};
-              __builtin_memcpy(yp, &v, 16);
+              __builtin_memcpy(reinterpret_cast<int*>(g.y) + yoff, &v, 16);
             } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (o + e >= skip && o + e < room) yp[e] = acc[t][4 * gq + e];
-            }
-          } else {
-            float f[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) f[e] = epilogue_f32(acc[t][4 * gq + e], sc, bi, g.act, g.alpha);
-            float* yp = reinterpret_cast<float*>(g.y) + yoff;
-            if (whole) {
-              const v4f v = {f[0], f[1], f[2], f[3]};
-              __builtin_memcpy(yp, &v, 16);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (o + e >= skip && o + e < room) yp[e] = f[e];
+              const v4f v = {epilogue_f32(acc[t][4 * gq], sc, bi, g.act, g.alpha), epilogue_f32(acc[t][4 * gq + 1], sc, bi, g.act, g.alpha),
+                             epilogue_f32(acc[t][4 * gq + 2], sc, bi, g.act, g.alpha), epilogue_f32(acc[t][4 * gq + 3], sc, bi, g.act, g.alpha)};
+              __builtin_memcpy(reinterpret_cast<float*>(g.y) + yoff, &v, 16);
             }
           }
         }
       }
     }
+  };
+
+  // step -1: K-step 0 has landed everywhere
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(2 * (A0 - 1)) : "memory");
+  __builtin_amdgcn_s_barrier();
+  PLHIP_WIDE_STAMP(4);
+  using std::integral_constant;
+  typedef integral_constant<int, 0> I0;
+  typedef integral_constant<int, TS> ITS;
+  typedef integral_constant<int, NTT> INT;
+  kpass(I0{}, ITS{}, integral_constant<bool, true>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last counted wait already was vmcnt(0))
+  PLHIP_WIDE_STAMP(5);
+  if (wave < 4) {  // one wave per SIMD each way
+    epass(I0{}, ITS{});
+    PLHIP_WIDE_STAMP(6);
+    kpass(ITS{}, INT{}, integral_constant<bool, false>{});
+    PLHIP_WIDE_STAMP(7);
+  } else {
+    kpass(ITS{}, INT{}, integral_constant<bool, false>{});
+    PLHIP_WIDE_STAMP(6);
+    epass(I0{}, ITS{});
+    PLHIP_WIDE_STAMP(7);
   }
+  epass(ITS{}, INT{});
+#undef PLHIP_WIDE_READ
   if (diag) {  // wave-uniform
-    PLHIP_WIDE_STAMP(7);  // epilogue instructions issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
       lstamp[8] = __builtin_amdgcn_s_memtime();  // stores acknowledged
@@ -367,8 +370,10 @@ static void cpi_magic(long d, unsigned& m, int& sh) {  // fastdiv_u31's (magic, 
 template <int NTT, int KS, int OUT>
 static void launch_wide_t(GemmArgs g, hipStream_t s) {
   constexpr int A0 = 4, R = 2;
-  constexpr int G = (NTT + 3) / 4, KSTEP = G * 4096, PITCH = NTT * 32 + 16;
-  constexpr int LDS_MAIN = KS * KSTEP > 8 * 32 * PITCH ? KS * KSTEP : 8 * 32 * PITCH;
+  constexpr int C1 = 2 * NTT > 8 ? 2 * NTT - 8 : 0, KSTEP = 4 * (1024 + C1 * 128);
+  constexpr int TS = NTT > 4 ? 4 : (NTT + 1) / 2, PITCH = TS * 32 + 16;
+  constexpr int LDS_MAIN = KS * KSTEP + 8 * 32 * PITCH;
+  static_assert(LDS_MAIN + 8 * WIDE_STAMP_SLOTS * 8 <= 160 * 1024, "LDS");
   const int CPI = (g.HWX + 15) >> 4;
   const long chunks = (long)g.NB * CPI;
   g.NT = (int)((chunks + 2 * NTT - 1) / (2 * NTT));
@@ -410,7 +415,10 @@ int gemm_wide_ntt(const GemmArgs& g) {
   for (int i = 0; i < 3; ++i) {
     const int ntt = cands[i];
     if (force && ntt != force) continue;
-    if ((long)g.KS * ((ntt + 3) / 4) * 4096 > 144 * 1024) continue;  // the activation tile must fit the LDS
+    {  // the activation tile + the staging images must fit the LDS (wide_lds_bytes)
+      const int c1 = 2 * ntt > 8 ? 2 * ntt - 8 : 0, ts = ntt > 4 ? 4 : (ntt + 1) / 2;
+      if ((long)g.KS * 4 * (1024 + c1 * 128) + 8 * 32 * (ts * 32 + 16) + 8 * WIDE_STAMP_SLOTS * 8 > 160 * 1024) continue;
+    }
     const long nblocks = (chunks + 2 * ntt - 1) / (2 * ntt);
     const long blocks = nblocks * mblocks;
     const long rounds = (blocks + 255) / 256;
@@ -442,10 +450,9 @@ bool launch_gemm_wide(const GemmArgs& g_in, int out, hipStream_t s) {
     else if (g.KS == 8) launch_wide_o<7, 8>(g, out, s);
     else launch_wide_o<7, 16>(g, out, s);
   } else {
-    if (g.KS == 32) return false;
+    if (g.KS >= 16) return false;
     if (g.KS == 4) launch_wide_o<8, 4>(g, out, s);
-    else if (g.KS == 8) launch_wide_o<8, 8>(g, out, s);
-    else launch_wide_o<8, 16>(g, out, s);
+    else launch_wide_o<8, 8>(g, out, s);
   }
 #undef PLHIP_WIDE_KS
   return true;

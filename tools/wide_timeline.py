@@ -68,11 +68,16 @@ def main():
             show("-> top of K-step 0 (fragments read)", t[:, 10] - t[:, 4])
             for i in range(ks - 1):
                 show("K-step %d" % i, t[:, 11 + i] - t[:, 10 + i])
-            show("last K-step -> loop end", t[:, 5] - t[:, 10 + ks - 1])
-            show("whole K loop", t[:, 5] - t[:, 4])
-            show("barrier + requantise + stage", t[:, 6] - t[:, 5])
-            show("read back + stores issued", t[:, 7] - t[:, 6])
-            show("store drain (vmcnt 0)", t[:, 8] - t[:, 7])
+            show("last K-step -> end of pass 1", t[:, 5] - t[:, 10 + ks - 1])
+            show("whole K loop, pass 1", t[:, 5] - t[:, 4])
+            wa = st[:, :4, :].reshape(-1, SLOTS)
+            wb = st[:, 4:, :].reshape(-1, SLOTS)
+            show("waves 0-3: epilogue 1", wa[:, 6] - wa[:, 5])
+            show("waves 0-3: K loop 2", wa[:, 7] - wa[:, 6])
+            show("waves 0-3: epilogue 2 + store drain", wa[:, 8] - wa[:, 7])
+            show("waves 4-7: K loop 2", wb[:, 6] - wb[:, 5])
+            show("waves 4-7: epilogue 1", wb[:, 7] - wb[:, 6])
+            show("waves 4-7: epilogue 2 + store drain", wb[:, 8] - wb[:, 7])
             show("wave total", t[:, 8] - t[:, 1])
             clk = (t[:, 8] - t[:, 1]).astype(np.float64) / np.maximum(1, (t[:, 9] - t[:, 0])) / 10.0
             print("  shader clock over wave lifetime: median %.2f GHz" % np.median(clk))
