@@ -63,8 +63,10 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="images per GPU and step (weak scaling); default: the config's")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
     ap.add_argument("--global-batch", type=int, default=None, help="strong scaling: images per step over all GPUs")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each, back to back; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the oracle comparison of the last step's output")
     ap.add_argument("--layer-table", action="store_true", help="print the per-instruction timing table to stderr")
     ap.add_argument("--inflight", type=int, default=3,
                     help="predictors per GPU, each on its own host thread + HIP stream, each running WHOLE steps; the steps "
@@ -95,8 +97,31 @@ def spawn_ranks(args):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # poll ALL children: a rank that dies before the rendezvous must not leave the others waiting in init_process_group
+    # (fresh processes only: nothing that touched the GPU is ever re-executed)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    out0 = (chunks[0] if chunks else b"").decode()
+    rcs = [p.wait() for p in procs]
     sys.stdout.write(out0)
     sys.stdout.flush()
     if any(rc != 0 for rc in rcs):
@@ -225,9 +250,55 @@ def cpu_baseline(cfg, net, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or done >= 100000:
             break
+    c1 = None
+    if cfg["model"] == "mobilenet_v1":
+        # BASELINE config C1 beside it: the same network in fp32 through the reference's x86 path restated (im2col + SGEMM per
+        # image and group, batch_norm / relu as separate fp32 passes; all-ones 1x3x224x224 input, test_mobilenetv1_lite_x86.cc)
+        from oracle import x86_path
+        c1 = x86_path.time_c1(net, seconds=min(4.0, max(1.0, seconds / 3)))
+        c1["cores"] = int(os.environ["OMP_NUM_THREADS"])
+        c1["note"] = ("MobileNetV1 fp32 1x3x%dx%d, oracle/x86_path.py: restatement of lite/kernels/x86/conv_compute.h:48-150 "
+                      "(the reference's x86 build needs MKLML / gflags / protobuf downloads: unbuildable here)" % (h, w))
     return {"value": round(done / el, 2), "unit": "img/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+            "fp32_x86_path_ms": c1["avg_ms"] if c1 else None, "fp32_x86_path": c1,
             "sample": "%d images of the same graph, batch 1 each, %.1f s; oracle/ restatement of the reference's im2col+GEMM int8 "
                       "path (its ARM NEON kernels cannot run on x86; its x86 backend has no INT8 kernels)" % (done, el)}
+
+
+def oracle_selfcheck(np, pred, net, cfg, images, out_var):
+    """Compare the predictor's variables for images[0:2] (the first rows of the last timed step) with oracle/ on the same
+    bytes.  Test infrastructure use of the oracle: the checker, never the thing measured."""
+    from oracle import graph_oracle, plref
+    n = images.shape[0]
+    if cfg["model"] == "conv":
+        o = net["ops"][0]
+        c, h, w = net["input_shape"]
+        sh = plref.shape(n, c, h, w, o["w"].shape[0], 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)
+        want, _ = plref.conv2d(sh, images, o["w"], o["bias"], float(o["in_scale"]), o["w_scale"], float(o["out_scale"]), 1, 0.0, True, via_gemm=True)
+        got = pred.get_var(out_var, np.int8)[:n]
+        bad = int((got != want).sum())
+        return {"ok": bad == 0, "images": n, "checked": {out_var: "int8 bit-exact"}, "mismatches": bad}
+    ref = graph_oracle.forward(plref, net, images, keep=None, via_gemm=True)
+    checked, bad = {}, 0
+    names = [v for v in ref if v != net["input"]]
+    # every int8 variable that survives in the lowered program, plus the fp32 output
+    for v in names:
+        if ref[v].dtype != np.int8 and v != out_var:
+            continue
+        try:
+            got = pred.get_var(v, ref[v].dtype, max_bytes=(1 << 30) if v == out_var else (96 << 20))[:n]
+        except Exception:  # noqa: BLE001  (fused away in the lowered program)
+            continue
+        if got.shape != ref[v].shape:
+            continue
+        if ref[v].dtype == np.int8:
+            nb = int((got != ref[v]).sum())
+            checked[v] = "int8 bit-exact"
+        else:
+            nb = int((~np.isclose(got, ref[v], rtol=1e-4, atol=1e-7)).sum())
+            checked[v] = "fp32 rtol 1e-4 atol 1e-7"
+        bad += nb
+    return {"ok": bad == 0 and out_var in checked, "images": n, "variables_checked": len(checked), "output": checked.get(out_var), "mismatches": bad}
 
 
 def main():
@@ -240,6 +311,8 @@ def main():
     if args.gpus != world:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
+    if os.environ.get("PLHIP_BENCH_DIE_RANK") == str(rank) and world > 1:  # tests only: a rank that dies before the rendezvous
+        sys.exit(7)
     # stdout carries exactly ONE line, the JSON record: everything else that libraries print there (RCCL's version banner,
     # c10d notices) is sent to stderr by pointing fd 1 at fd 2 and keeping the real stdout aside
     sys.stdout.flush()
@@ -317,6 +390,7 @@ def main():
             images = rng.integers(-127, 128, (global_batch, c, h, w)).astype(np.int8)
         else:
             images = rng.uniform(-1, 1, (global_batch, c, h, w)).astype(np.float32)
+    check_images = images[:2].copy() if images is not None else None  # rank 0's shard starts at image 0
     if dry:
         image = None
     elif cfg["model"] == "conv":
@@ -435,15 +509,22 @@ def main():
             torch.cuda.synchronize(dev)
 
     run_steps(args.warmup)
-    sync_all()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # EXACTLY args.steps steps per timed window, barrier + synchronize on both sides (the contract); the window is repeated
+    # back to back and the MEDIAN window is reported: a single 20-step window is ~9 ms here and moved the figure by 3-7 %
+    # from run to run.  min / median / max over the windows are in the line.
+    wins = []
+    for _ in range(max(1, args.windows)):
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        sync_all()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        wins.append(el)
+    elapsed = float(np.median(wins))
 
     # ---- outside the timed region: the gathered result of the last step is complete and in rank-major image order ----
     if use_dist and last_gather[0] is not None:
@@ -550,6 +631,17 @@ def main():
                         "summed over the family's launches of one step, / summed launch time (HIP events on the launch "
                         "stream, 4 launches per event pair); bound = mfma iff ops/byte > %.0f" % BALANCE_OPS_PER_BYTE}
 
+    # ---- self-check, outside the timed region: what the timed program computed for the first two images of this rank's
+    # shard must equal the oracle's result for the same bytes (int8 tensors bit for bit, fp32 within the tolerance of the
+    # parity tests); a mismatch makes the run fail instead of printing a rate for garbage
+    selfcheck = None
+    if rank == 0 and not dry and check_images is not None and not args.no_selfcheck:
+        selfcheck = oracle_selfcheck(np, pred, net, cfg, check_images, eng0.out_var)
+        if not selfcheck["ok"]:
+            sys.stderr.write("bench.py: SELF-CHECK FAILED: %s\n" % json.dumps(selfcheck))
+            real_stdout.flush()
+            os._exit(3)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         cpu = cpu_baseline(cfg, net, args.cpu_seconds)
@@ -574,6 +666,10 @@ def main():
                                 "(see single_stream)" % P,
             "whole_graph_TOP/s": round(val * ops_per_img / 1e12, 2),
             "whole_graph_frac_of_i8_mfma_peak": round(val * ops_per_img / 1e12 / MFMA_I8_PEAK_TOPS, 4),
+            "windows": {"count": len(wins), "steps_each": args.steps,
+                        "ms_per_step_min_median_max": [round(1e3 * min(wins) / args.steps, 4), round(1e3 * elapsed / args.steps, 4),
+                                                       round(1e3 * max(wins) / args.steps, 4)]},
+            "selfcheck": selfcheck,
             "single_stream": serial, "roofline": roof, "kernels": fam_out, "cpu_baseline": cpu,
         }
         real_stdout.write(json.dumps(line) + "\n")

@@ -334,3 +334,87 @@ void plref_elementwise_add_f32(const float* x, const float* y, float* out, int64
     out[i] = r;
   }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * BASELINE config C1: the reference's x86 fp32 path (CxxPredictor plumbing, no GPU), restated for timing beside the
+ * GPU number and for the plumbing check.  Parity UNPINNED beyond 1e-5 relative: the reference's GEMM is MKLML's
+ * cblas_sgemm (mklml_lnx_2019.0.1.20181227, absent here), whose summation order is not specified.
+ *
+ * lite/kernels/x86/conv_compute.h:48-150: per image and group, im2col (kCFO: [c][kh][kw][oh][ow],
+ * lite/backends/x86/math/im2col.cc:31-57; skipped for 1x1 stride 1 pad 0: IsExpand :31-46) then
+ * out[g] (out_step x OH*OW) = filter[g] (out_step x K) . col (K x OH*OW)   (Blas::MatMul -> cblas_sgemm,
+ * lite/backends/x86/math/blas_impl.h:38,459-).  The kernel adds NO bias and applies NO activation: batch_norm and relu
+ * are separate fp32 instructions of the x86 program.  depthwise_conv2d is registered on the same class
+ * (lite/kernels/x86/conv_compute.cc), i.e. a 1 x 9 GEMM per group. */
+void plref_im2col_f32(const float* x, int cin_g, int h, int w, int kh, int kw, int pt, int pl, int sh, int sw, int dh,
+                      int dw, int oh, int ow, float* col) {
+  const int n = oh * ow;
+#pragma omp parallel for schedule(static) if ((int64_t)cin_g * kh * kw * n > 65536)
+  for (int r = 0; r < cin_g * kh * kw; ++r) {
+    const int q = r % kw, p = (r / kw) % kh, c = r / (kw * kh);
+    float* dst = col + (int64_t)r * n;
+    for (int y = 0; y < oh; ++y) {
+      const int ih = y * sh - pt + p * dh;
+      for (int xo = 0; xo < ow; ++xo) {
+        const int iw = xo * sw - pl + q * dw;
+        dst[y * ow + xo] = (ih >= 0 && ih < h && iw >= 0 && iw < w) ? x[((int64_t)c * h + ih) * w + iw] : 0.f;
+      }
+    }
+  }
+}
+
+/* C (m x n) = A (m x k) . B (k x n), row-major, alpha 1, beta 0; k ascending per output element */
+void plref_sgemm_f32(int m, int n, int k, const float* a, const float* b, float* c) {
+#pragma omp parallel for schedule(static) if ((int64_t)m * n * k > 65536 && m > 1)
+  for (int i = 0; i < m; ++i) {
+    float* ci = c + (int64_t)i * n;
+    for (int j = 0; j < n; ++j) ci[j] = 0.f;
+    for (int p = 0; p < k; ++p) {
+      const float av = a[(int64_t)i * k + p];
+      const float* bp = b + (int64_t)p * n;
+      for (int j = 0; j < n; ++j) ci[j] += av * bp[j];
+    }
+  }
+}
+
+/* col: caller-provided scratch of (cin/groups)*kh*kw*oh*ow floats (unused for 1x1 stride 1 pad 0) */
+void plref_conv2d_f32_x86(const plref_conv_shape* s, const float* x, const float* w, float* y, float* col) {
+  int oh, ow;
+  plref_conv_out_dims(s, &oh, &ow);
+  const int g = s->groups, in_step = s->cin / g, out_step = s->cout / g;
+  const int kk = in_step * s->kh * s->kw, n = oh * ow;
+  const int expand = !(s->kh == 1 && s->kw == 1 && s->stride[0] == 1 && s->stride[1] == 1 && s->pad[0] == 0 &&
+                       s->pad[2] == 0 && s->dil[0] == 1 && s->dil[1] == 1);
+  for (int b = 0; b < s->n; ++b) {
+    for (int grp = 0; grp < g; ++grp) {
+      const float* in_slice = x + ((int64_t)b * s->cin + (int64_t)grp * in_step) * s->h * s->w;
+      const float* cm = in_slice;
+      if (expand) {
+        /* conv_compute.h:113-121 passes {paddings[0], paddings[2], paddings[0], paddings[2]}: top / left pads for both sides */
+        plref_im2col_f32(in_slice, in_step, s->h, s->w, s->kh, s->kw, s->pad[0], s->pad[2], s->stride[0], s->stride[1],
+                         s->dil[0], s->dil[1], oh, ow, col);
+        cm = col;
+      }
+      plref_sgemm_f32(out_step, n, kk, w + (int64_t)grp * out_step * kk, cm,
+                      y + ((int64_t)b * s->cout + (int64_t)grp * out_step) * n);
+    }
+  }
+}
+
+/* lite/kernels/x86/batch_norm_compute.h:43-161 (is_test: y = (x - mean) / sqrt(var + eps) * scale + bias), with the relu
+ * that follows it in MobileNetV1 applied in the same pass when relu != 0 (lite/kernels/x86/activation_compute.h) */
+void plref_batch_norm_f32(const float* x, float* y, int n, int c, int spatial, const float* scale, const float* bias,
+                          const float* mean, const float* var, float eps, int relu) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n * c; ++i) {
+    const int ch = i % c;
+    const float inv = 1.f / sqrtf(var[ch] + eps);
+    const float a = inv * scale[ch], bb = bias[ch] - mean[ch] * inv * scale[ch];
+    const float* xp = x + (int64_t)i * spatial;
+    float* yp = y + (int64_t)i * spatial;
+    for (int j = 0; j < spatial; ++j) {
+      float v = xp[j] * a + bb;
+      yp[j] = relu ? (v > 0.f ? v : 0.f) : v;
+    }
+  }
+}

@@ -120,6 +120,16 @@ void plref_elementwise_add_f32(const float* x, const float* y, float* out, int64
 /* round-half-away + saturate helpers exposed for host-side bit tricks tests. */
 int8_t plref_round_sat_i8(float v);
 
+
+/* BASELINE config C1: the reference's x86 fp32 conv path (lite/kernels/x86/conv_compute.h:48-150: im2col + SGEMM, no
+ * bias / activation in the kernel), batch_norm (+relu).  Timing / plumbing restatement; parity unpinned beyond 1e-5. */
+void plref_im2col_f32(const float* x, int cin_g, int h, int w, int kh, int kw, int pt, int pl, int sh, int sw, int dh,
+                      int dw, int oh, int ow, float* col);
+void plref_sgemm_f32(int m, int n, int k, const float* a, const float* b, float* c);
+void plref_conv2d_f32_x86(const plref_conv_shape* s, const float* x, const float* w, float* y, float* col);
+void plref_batch_norm_f32(const float* x, float* y, int n, int c, int spatial, const float* scale, const float* bias,
+                          const float* mean, const float* var, float eps, int relu);
+
 #ifdef __cplusplus
 }
 #endif

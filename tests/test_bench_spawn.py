@@ -51,3 +51,15 @@ def test_single_process_line_shape():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line
     assert line["n_gpus"] == 1 and line["config"]["name"] == "c3"
+
+
+def test_a_rank_dying_before_the_rendezvous_ends_the_launch_quickly():
+    """spawn_ranks polls every child: rank 1 exits 7 before init_process_group, rank 0 would otherwise sit in the c10d
+    rendezvous until its timeout; the launcher must terminate it and return non-zero within seconds."""
+    import time
+    t0 = time.time()
+    rc, out, err = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--res", "32"],
+                        {"PLHIP_BENCH_DIE_RANK": "1"}, timeout=120)
+    assert rc != 0 and "rank exit codes" in err
+    assert time.time() - t0 < 60
+    assert not [l for l in out.splitlines() if l.startswith("{")]

@@ -66,18 +66,15 @@ def main():
             show("entry -> all loads issued", t[:, 3] - t[:, 1])
             show("-> K-step 0 landed everywhere", t[:, 4] - t[:, 3])
             show("-> top of K-step 0 (fragments read)", t[:, 10] - t[:, 4])
-            for i in range(ks - 1):
-                show("K-step %d" % i, t[:, 11 + i] - t[:, 10 + i])
-            show("last K-step -> end of pass 1", t[:, 5] - t[:, 10 + ks - 1])
-            show("whole K loop, pass 1", t[:, 5] - t[:, 4])
-            wa = st[:, :4, :].reshape(-1, SLOTS)
-            wb = st[:, 4:, :].reshape(-1, SLOTS)
-            show("waves 0-3: epilogue 1", wa[:, 6] - wa[:, 5])
-            show("waves 0-3: K loop 2", wa[:, 7] - wa[:, 6])
-            show("waves 0-3: epilogue 2 + store drain", wa[:, 8] - wa[:, 7])
-            show("waves 4-7: K loop 2", wb[:, 6] - wb[:, 5])
-            show("waves 4-7: epilogue 1", wb[:, 7] - wb[:, 6])
-            show("waves 4-7: epilogue 2 + store drain", wb[:, 8] - wb[:, 7])
+            a0, r = 4, 2
+            s1 = min(ks, (ks - a0 + r - 1) // r + 2)
+            for i in range(s1 - 1):
+                show("phase 1 K-step %d" % i, t[:, 11 + i] - t[:, 10 + i])
+            show("last phase-1 K-step", t[:, 5] - t[:, 10 + s1 - 1])
+            show("whole phase 1 (%d K-steps, all tiles)" % s1, t[:, 5] - t[:, 4])
+            show("phase 2: tile 0 (%d MFMAs, no epilogue)" % (ks - s1), t[:, 6] - t[:, 5])
+            show("phase 2: other tiles + epilogues", t[:, 7] - t[:, 6])
+            show("last tile's epilogue + store drain", t[:, 8] - t[:, 7])
             show("wave total", t[:, 8] - t[:, 1])
             clk = (t[:, 8] - t[:, 1]).astype(np.float64) / np.maximum(1, (t[:, 9] - t[:, 0])) / 10.0
             print("  shader clock over wave lifetime: median %.2f GHz" % np.median(clk))
