@@ -1,0 +1,14 @@
+// gemm_wide_n4.hip — the wide-tile GEMM (gemm_wide_i8.hip / gemm_wide_kernel.h) with 4 n tiles per block: its own
+// translation unit so that the instantiations compile in parallel.
+#include "gemm_wide_kernel.h"
+
+namespace plhip {
+
+void launch_wide_n4(const GemmArgs& g, int out, hipStream_t s) {
+  if (g.KS == 4) launch_wide_o<4, 4>(g, out, s);
+  else if (g.KS == 8) launch_wide_o<4, 8>(g, out, s);
+  else if (g.KS == 16) launch_wide_o<4, 16>(g, out, s);
+  else if (g.KS == 32) launch_wide_o<4, 32>(g, out, s);
+}
+
+}  // namespace plhip

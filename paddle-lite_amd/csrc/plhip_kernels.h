@@ -42,6 +42,7 @@ struct GemmArgs {
   // wide-tile kernel (gemm_wide_i8.hip): fastdiv_u31's (magic, shift) for the chunks per image, set by its launcher
   unsigned cpi_m;
   int cpi_s;
+  unsigned long long* stamps;  // its diagnostic timeline buffer (PLHIP_GEMM_DEBUG & 32) or nullptr
 };
 
 struct PadArgs {
@@ -118,7 +119,10 @@ int gemm_tr_enabled();
 bool launch_gemm_wide(const GemmArgs& g, int out, hipStream_t s);
 int gemm_wide_ntt(const GemmArgs& g);  // n tiles per block it would use, 0 = not taken
 int debug_read_wide_stamps(void* dst, size_t bytes);
-void debug_set_wide_ntt(int v);  // 4 / 7 / 8 force that tile, 0 = automatic, -1 = back to the environment's choice
+void debug_set_wide_ntt(int v);
+void launch_wide_n4(const GemmArgs& g, int out, hipStream_t s);  // per-tile translation units (gemm_wide_n*.hip)
+void launch_wide_n7(const GemmArgs& g, int out, hipStream_t s);
+void launch_wide_n8(const GemmArgs& g, int out, hipStream_t s);  // 4 / 7 / 8 force that tile, 0 = automatic, -1 = back to the environment's choice
 void launch_pack_weights(const int8_t* w, int8_t* wp, int G, int Mg, int Kg, int MT32, int KS, hipStream_t s);
 void launch_im2col(const Im2colArgs& a, hipStream_t s);
 int launch_depthwise(const DwArgs& a, int out, hipStream_t s);  // returns 0 or -3 (unsupported LDS size)
