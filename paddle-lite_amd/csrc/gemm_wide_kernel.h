@@ -39,12 +39,48 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
   constexpr int KSTEP = 4 * (1024 + P1);           // LDS bytes of one K-step: [group 0: 4 kg x 1024][group 1: 4 kg x P1]
   constexpr int TILE_BYTES = KS * KSTEP;
   constexpr int SP = 48;                           // staging row pitch: 32 bytes + 16 (odd multiple of 16: conflict-free row writes)
-  constexpr int ALL_ISSUED = (KS - A0 + R - 1) / R;              // first K-step that starts with every load issued
-  constexpr int S1 = ALL_ISSUED + 2 < KS ? ALL_ISSUED + 2 : KS;  // phase 1 = K-steps [0, S1)
-  constexpr int NG = KS - S1;                                    // MFMAs per tile in phase 2
-  constexpr int Q = NTT * NG;                                    // MFMAs of phase 2
-  constexpr int SPG = NG > 0 ? (16 + NG - 1) / NG : 16;          // epilogue slices per MFMA
-  static_assert((C1 == 0 || C1 == 6 || C1 == 8) && NTT >= 2 && NTT <= 8 && A0 >= 2 && A0 <= KS && R >= 1 && R <= NTT && S1 >= 2, "tile");
+  // phase 1 = K-steps [0, S1) of the tiles [0, TK), K-outer, while the operands arrive; phase 2 = everything else, tile by
+  // tile.  Measured on MobileNetV1's layers (profiles/r03_wide_timeline_v3/v5_pw8.txt, r03_ab_pw_v3_v5.txt): K >= 512: all
+  // tiles, half the K-steps (phase 1 keeps the matrix pipe fed while the loads issue; 8 MFMAs per tile are left to carry
+  // the epilogue slices); K <= 256: two tiles, the whole K (few K-steps: a phase 1 over all tiles would leave phase 2
+  // 2-4 MFMAs per tile for 16 slices).
+  constexpr int ALL_ISSUED = (KS - A0 + R - 1) / R;  // first K-step that starts with every load issued
+  constexpr bool DEEP = KS >= 16;
+  constexpr int TK = DEEP ? NTT : (NTT >= 6 ? 2 : 1);
+  constexpr int S1 = DEEP ? (ALL_ISSUED + 2 < KS ? ALL_ISSUED + 2 : KS) : KS;
+  constexpr int Q = TK * (KS - S1) + (NTT - TK) * KS;                        // MFMAs of phase 2
+  // flat phase-2 index -> tile (tile-major) and K-step
+  constexpr auto p2tile = [](int i) {
+    int t = 0;
+    while (t < NTT - 1 && i >= KS - (t < TK ? S1 : 0)) {
+      i -= KS - (t < TK ? S1 : 0);
+      ++t;
+    }
+    return t;
+  };
+  constexpr auto p2ks = [](int i) {
+    int t = 0;
+    while (t < NTT - 1 && i >= KS - (t < TK ? S1 : 0)) {
+      i -= KS - (t < TK ? S1 : 0);
+      ++t;
+    }
+    return (t < TK ? S1 : 0) + i;
+  };
+  constexpr int HID = 16 * (NTT - 1);              // epilogue slices to hide behind them (all tiles but the last)
+  // slices done when phase-2 MFMA gi has been issued: spread evenly, never ahead of the finished tiles (the tiles below
+  // the one MFMA gi - 1 belongs to)
+  constexpr auto cursor = [](int gi) {
+    if (gi <= 0 || Q == 0) return 0;
+    int want = (int)(((long)gi * HID + Q - 1) / Q);
+    int t = 0, i = gi - 1;
+    while (t < NTT - 1 && i >= KS - (t < TK ? S1 : 0)) {
+      i -= KS - (t < TK ? S1 : 0);
+      ++t;
+    }
+    const int cap = 16 * t;
+    return want < cap ? want : cap;
+  };
+  static_assert((C1 == 0 || C1 == 6 || C1 == 8) && NTT >= 2 && NTT <= 8 && A0 >= 2 && A0 <= KS && R >= 1 && R <= TK + 1 && S1 >= 2 && Q > 0, "tile");
   constexpr auto issued_before = [](int ks) { return A0 + R * ks < KS ? A0 + R * ks : KS; };  // K-steps issued when step ks starts
   PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.x); PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias);
   PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.HWX); PLHIP_PRELOAD(g.HWY); PLHIP_PRELOAD(g.XP); PLHIP_PRELOAD(g.NB);
@@ -147,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
       tr0[tt] = ring_addr + (h * 2) * 1024 + qr * 128 + ((2 * (tt ^ (qr >> 1)) + par) * 16) + (lane & 1) * 8;
     tr1 = ring_addr + 4096 + (h * 2) * P1 + qr * 96 + par * 16 + (lane & 1) * 8;  // 6-slot group 1
   }
-  constexpr int NF = NTT > 3 ? NTT : 3;  // fragment registers: one set per tile in phase 1, a ring of 3 sets in phase 2
+  constexpr int NF = TK > 3 ? TK : 3;  // fragment registers: one set per tile in phase 1, a ring of 3 sets in phase 2
   v2i lo[NF], hi[NF];
   v16i acc[NTT];
 #pragma unroll
@@ -169,8 +205,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
 
   using std::integral_constant;
   // ---------------------------------------------------------------------------------------------------------------
-  // phase 1: K-steps [0, S1), all tiles.  Top of step ks: K-step ks+1 has landed (my loads of it: counted vmcnt; everyone's:
-  // barrier); the last step waits for EVERYTHING, so that phase 2 needs no wait on memory.
+  // phase 1: the whole K of the tiles [0, TK), K-outer.  Top of step ks: K-step ks+1 has landed (my loads of it: counted
+  // vmcnt; everyone's: barrier); when it ends every operand byte of the block is in LDS / registers: phase 2 has no wait on
+  // memory and no barrier.
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(2 * (A0 - 1)) : "memory");
   __builtin_amdgcn_s_barrier();
   PLHIP_WIDE_STAMP(4);
@@ -180,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
       if constexpr (ks == 0) {  // fragments of K-step 0
         auto rd = [&](auto rself, auto t_c) __attribute__((always_inline)) -> void {
           constexpr int t = decltype(t_c)::value;
-          if constexpr (t < NTT) {
+          if constexpr (t < TK) {
             PLHIP_WIDE_READ(0, t, t);
             rself(rself, integral_constant<int, t + 1>{});
           }
@@ -201,18 +238,19 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
           for (int i = S1; i < KS; ++i) asm volatile("" : "+v"(w[i]));  // no use of a later fragment above this wait
           __builtin_amdgcn_s_barrier();
         }
-        PLHIP_WIDE_STAMP(10 + ks);
+        if constexpr (ks < 20) PLHIP_WIDE_STAMP(10 + ks);
         auto mm = [&](auto mself, auto t_c) __attribute__((always_inline)) -> void {
           constexpr int t = decltype(t_c)::value;
-          if constexpr (t < NTT) {
+          if constexpr (t < TK) {
             // fragment t of this K-step: reads issued behind it = tiles t+1.. of this step and 0..t-1 of the next
-            constexpr int yl = NEXT ? 2 * (NTT - 1) : 2 * (NTT - 1 - t);
+            constexpr int yl = NEXT ? 2 * (TK - 1) : 2 * (TK - 1 - t);
             asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo[t]), "+v"(hi[t]) : "n"(yl) : "memory");
             const v4i a = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
             acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w[ks], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);  // the MFMA stays between its fragment's wait and the next read
             if constexpr (NEXT) PLHIP_WIDE_READ(ks + 1, t, t);
             if constexpr (issued_before(ks) + t < issued_before(ks + 1)) issue(issued_before(ks) + t);
+            if constexpr (t == TK - 1 && issued_before(ks) + TK < issued_before(ks + 1)) issue(issued_before(ks) + TK);
             __builtin_amdgcn_sched_barrier(0);
             mself(mself, integral_constant<int, t + 1>{});
           }
@@ -223,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
     };
     kstep(kstep, integral_constant<int, 0>{});
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last counted wait already was vmcnt(0))
   PLHIP_WIDE_STAMP(5);
 
   // ---------------------------------------------------------------------------------------------------------------
@@ -297,45 +336,35 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
       }
     }
   };
-  auto slices = [&](auto self, auto t_c, auto r_c, auto rend_c) __attribute__((always_inline)) -> void {
-    constexpr int t = decltype(t_c)::value, r = decltype(r_c)::value, rend = decltype(rend_c)::value;
-    if constexpr (r < rend && r < 16) {
-      slice(integral_constant<int, t>{}, integral_constant<int, r>{});
-      self(self, integral_constant<int, t>{}, integral_constant<int, r + 1>{}, integral_constant<int, rend>{});
+  auto runslices = [&](auto self, auto e_c, auto eend_c) __attribute__((always_inline)) -> void {
+    constexpr int e = decltype(e_c)::value, eend = decltype(eend_c)::value;
+    if constexpr (e < eend) {
+      slice(integral_constant<int, e / 16>{}, integral_constant<int, e % 16>{});
+      self(self, integral_constant<int, e + 1>{}, integral_constant<int, eend>{});
     }
   };
-  if constexpr (Q > 0) {
-    PLHIP_WIDE_READ(S1, 0, 0);
-    if constexpr (Q > 1) PLHIP_WIDE_READ(S1 + (1 % NG), 1 / NG, 1);
+  {
+    PLHIP_WIDE_READ(p2ks(0), p2tile(0), 0);
+    if constexpr (Q > 1) PLHIP_WIDE_READ(p2ks(1), p2tile(1), 1);
     auto mm2 = [&](auto self, auto i_c) __attribute__((always_inline)) -> void {
       constexpr int i = decltype(i_c)::value;
       if constexpr (i < Q) {
-        constexpr int t = i / NG, j = i % NG, f = i % 3;
+        constexpr int t = p2tile(i), j = p2ks(i), f = i % 3;
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo[f]), "+v"(hi[f]) : "n"(i + 1 < Q ? 2 : 0) : "memory");
         const v4i a = {lo[f][0], lo[f][1], hi[f][0], hi[f][1]};
-        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w[S1 + j], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w[j], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (i + 2 < Q) PLHIP_WIDE_READ(S1 + ((i + 2) % NG), (i + 2) / NG, (i + 2) % 3);
-        if constexpr (t > 0) slices(slices, integral_constant<int, t - 1>{}, integral_constant<int, j * SPG>{}, integral_constant<int, (j + 1) * SPG>{});
+        if constexpr (i + 2 < Q) PLHIP_WIDE_READ(p2ks(i + 2), p2tile(i + 2), (i + 2) % 3);
+        runslices(runslices, integral_constant<int, cursor(i)>{}, integral_constant<int, cursor(i + 1)>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (j == NG - 1 && t == 0) PLHIP_WIDE_STAMP(6);
+        if constexpr (j == KS - 1 && t < 16) PLHIP_WIDE_STAMP(30 + t);
         self(self, integral_constant<int, i + 1>{});
       }
     };
     mm2(mm2, integral_constant<int, 0>{});
-  } else {
-    // K <= 64: no phase 2; every tile's epilogue runs here
-    auto alle = [&](auto self, auto t_c) __attribute__((always_inline)) -> void {
-      constexpr int t = decltype(t_c)::value;
-      if constexpr (t < NTT - 1) {
-        slices(slices, integral_constant<int, t>{}, integral_constant<int, 0>{}, integral_constant<int, 16>{});
-        self(self, integral_constant<int, t + 1>{});
-      }
-    };
-    alle(alle, integral_constant<int, 0>{});
+    PLHIP_WIDE_STAMP(7);
+    runslices(runslices, integral_constant<int, cursor(Q)>{}, integral_constant<int, 16 * NTT>{});  // what is left: the last tile at least
   }
-  PLHIP_WIDE_STAMP(7);
-  slices(slices, integral_constant<int, NTT - 1>{}, integral_constant<int, 0>{}, integral_constant<int, 16>{});  // the exposed one
 #undef PLHIP_WIDE_READ
   if (diag) {  // wave-uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,6 +1,7 @@
 // hip_predictor.cc — see hip_predictor.h.
 #include "lite/api/hip_predictor.h"
 
+#include "lite/kernels/hip/conv_fusion.h"
 #include "plhip.h"
 
 #include <cstring>
@@ -77,6 +78,8 @@ void HipPredictor::AddConv(const std::string& op_type, const std::string& in, co
                            const std::vector<int64_t>& w_dims, const float* bias, const ConvAttrs& a) {
   auto op = std::make_shared<operators::ConvOpLite>(op_type);
   auto& p = op->mutable_param();
+  kernels::hip::HipConvFusion fz;  // this target's graph-level fusion state (lite/kernels/hip/conv_fusion.h)
+  const bool fused = !a.calib_out.empty() || !a.residual.empty() || a.pw_w != nullptr;
   size_t wn = 1;
   for (auto d : w_dims) wn *= static_cast<size_t>(d);
   p.x = Var(in);
@@ -102,34 +105,41 @@ void HipPredictor::AddConv(const std::string& op_type, const std::string& in, co
     CHECK(!a.int8_out) << "the fused residual add belongs to the fp32_out kernel";
     p.fuse_residual_connection = true;
     p.residualData = Var(a.residual);
-    p.fuse_residual_relu = a.residual_relu;
+    fz.fuse_residual_relu = a.residual_relu;
   }
   if (!a.calib_out.empty()) {
     CHECK(!a.int8_out) << "the fused calib belongs to the fp32_out kernel";
-    p.calib_output = Var(a.calib_out);
-    p.calib_output->set_precision(PRECISION(kInt8));
-    p.calib_scale = a.calib_scale;
-    p.drop_fp32_output = a.drop_fp32;
+    fz.calib_output = Var(a.calib_out);
+    fz.calib_output->set_precision(PRECISION(kInt8));
+    fz.calib_scale = a.calib_scale;
+    fz.drop_fp32_output = a.drop_fp32;
   }
   if (a.pw_w) {
     CHECK(a.int8_out && op_type == "depthwise_conv2d") << "only a depthwise conv with int8 output takes a 1x1 consumer over";
     size_t pn = 1;
     for (auto d : a.pw_w_dims) pn *= static_cast<size_t>(d);
-    p.pw_filter = NewParam(a.pw_w, pn, a.pw_w_dims, PRECISION(kInt8));
-    p.pw_bias = a.pw_bias ? NewParam(a.pw_bias, static_cast<size_t>(a.pw_w_dims[0]) * 4, {a.pw_w_dims[0]}, PRECISION(kFloat)) : nullptr;
-    p.pw_weight_scale = a.pw_weight_scale;
-    p.pw_output_scale = a.pw_output_scale;
-    p.pw_int8_out = a.pw_int8_out;
+    fz.pw_filter = NewParam(a.pw_w, pn, a.pw_w_dims, PRECISION(kInt8));
+    op->set_output_channels(a.pw_w_dims[0]);
+    fz.pw_bias = a.pw_bias ? NewParam(a.pw_bias, static_cast<size_t>(a.pw_w_dims[0]) * 4, {a.pw_w_dims[0]}, PRECISION(kFloat)) : nullptr;
+    fz.pw_weight_scale = a.pw_weight_scale;
+    fz.pw_output_scale = a.pw_output_scale;
+    fz.pw_int8_out = a.pw_int8_out;
     if (a.pw_act != 0) {
-      p.pw_activation_param.has_active = true;
-      p.pw_activation_param.active_type = static_cast<lite_api::ActivationType>(a.pw_act);
-      if (a.pw_act == 2) p.pw_activation_param.Relu_clipped_coef = a.pw_act_coef;
-      if (a.pw_act == 4) p.pw_activation_param.Leaky_relu_alpha = a.pw_act_coef;
+      fz.pw_activation_param.has_active = true;
+      fz.pw_activation_param.active_type = static_cast<lite_api::ActivationType>(a.pw_act);
+      if (a.pw_act == 2) fz.pw_activation_param.Relu_clipped_coef = a.pw_act_coef;
+      if (a.pw_act == 4) fz.pw_activation_param.Leaky_relu_alpha = a.pw_act_coef;
     }
     p.output->set_precision(a.pw_int8_out ? PRECISION(kInt8) : PRECISION(kFloat));
   }
   op->set_padding_algorithm(a.padding_algorithm);
-  Emit(op, PickKernel(op_type, Place(TARGET(kHIP), PRECISION(kInt8)), a.int8_out ? "int8_out" : "fp32_out"));
+  auto kernel = PickKernel(op_type, Place(TARGET(kHIP), PRECISION(kInt8)), a.int8_out ? "int8_out" : "fp32_out");
+  if (fused) {  // this target's fusion state goes to the kernel object, not into the reference's ConvParam (conv_fusion.h)
+    auto* fk = dynamic_cast<kernels::hip::HipFusableKernel*>(kernel.get());
+    CHECK(fk) << "the picked conv kernel does not take a kHIP fusion";
+    fk->SetFusion(fz);
+  }
+  Emit(op, std::move(kernel));
 }
 
 void HipPredictor::AddFc(const std::string& in, const std::string& out, const int8_t* w, int k, int n, const float* bias,

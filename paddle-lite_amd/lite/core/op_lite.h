@@ -60,6 +60,7 @@ class ConvOpLite : public OpLite {
   explicit ConvOpLite(const std::string& type = "conv2d") : OpLite(type) {}
   ConvParam& mutable_param() { return param_; }
   void set_padding_algorithm(const std::string& a) { padding_algorithm_ = a; }
+  void set_output_channels(int64_t c) { out_channels_override_ = c; }  // kHIP fusions only (lite/kernels/hip/conv_fusion.h)
   bool CheckShape() const override {
     CHECK(param_.x && param_.filter && param_.output) << "conv: x / filter / output must be set";
     const auto in = param_.x->dims(), f = param_.filter->dims();
@@ -79,8 +80,8 @@ class ConvOpLite : public OpLite {
   bool InferShapeImpl() const override {
     const auto in = param_.x->dims(), f = param_.filter->dims();
     UpdatePaddingAndDilation(param_.paddings.get(), param_.dilations.get(), param_.strides, padding_algorithm_, in, f);
-    // kHIP fusion: a depthwise conv that took its 1x1 consumer over writes THAT conv's output: pw_filter.dims[0] channels
-    std::vector<int64_t> out{in[0], param_.pw_filter ? param_.pw_filter->dims()[0] : f[0]};
+    // kHIP dw -> pw fusion (opt-in): a depthwise conv that took its 1x1 consumer over writes THAT conv's output
+    std::vector<int64_t> out{in[0], out_channels_override_ > 0 ? out_channels_override_ : f[0]};
     for (size_t i = 0; i < param_.strides.size(); ++i)
       out.push_back(ConvOutputSize(static_cast<int>(in[i + 2]), static_cast<int>(f[i + 2]), (*param_.dilations)[i],
                                    (*param_.paddings)[i * 2], (*param_.paddings)[i * 2 + 1], param_.strides[i]));
@@ -92,6 +93,7 @@ class ConvOpLite : public OpLite {
  private:
   mutable ConvParam param_;
   std::string padding_algorithm_{""};
+  int64_t out_channels_override_{0};
 };
 
 class FcOpLite : public OpLite {

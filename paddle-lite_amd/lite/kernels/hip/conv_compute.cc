@@ -57,7 +57,7 @@ void ConvCompute<Ptype, OutType>::ReInitWhenNeeded() {
     pw_desc_.n = desc_.n;
     pw_desc_.h = static_cast<int>(od[2]);
     pw_desc_.w = static_cast<int>(od[3]);
-    pw_fused_ = plhip_dwpw_fused_supported(&desc_, pw_desc_.cout, param.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32) != 0;
+    pw_fused_ = plhip_dwpw_fused_supported(&desc_, pw_desc_.cout, fusion_.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32) != 0;
     kernel_func_name_ = pw_fused_ ? "conv_depthwise_3x3_pointwise_1x1_fused_int8_hip" : "conv_depthwise_int8_hip+conv1x1s1_gemm_int8_mfma32x32x32";
   }
   last_shape_ = param.x->dims();
@@ -70,7 +70,7 @@ void ConvCompute<Ptype, OutType>::PreparePointwise() {
   auto& param = this->template Param<param_t>();
   auto& ctx = this->ctx_->template As<HIPContext>();
   CHECK(is_depthwise_ && OutType == PRECISION(kInt8)) << "kHIP: only a depthwise conv with int8 output takes a 1x1 consumer over";
-  const auto wd = param.pw_filter->dims();
+  const auto wd = fusion_.pw_filter->dims();
   CHECK(wd.size() == 4UL && wd[2] == 1 && wd[3] == 1 && wd[1] == desc_.cout) << "fused consumer must be a 1x1 conv over the depthwise channels";
   const int m = static_cast<int>(wd[0]);
   pw_desc_ = plhip_conv_desc{};
@@ -79,7 +79,7 @@ void ConvCompute<Ptype, OutType>::PreparePointwise() {
   pw_desc_.stride[0] = pw_desc_.stride[1] = 1;
   pw_desc_.dil[0] = pw_desc_.dil[1] = 1;
   pw_desc_.groups = 1;
-  const auto& act = param.pw_activation_param;
+  const auto& act = fusion_.pw_activation_param;
   float alpha = 0.f;
   pw_desc_.act = PLHIP_ACT_NONE;
   if (act.has_active) {
@@ -90,28 +90,28 @@ void ConvCompute<Ptype, OutType>::PreparePointwise() {
       default: LOG(FATAL) << "this act_type: " << static_cast<int>(act.active_type) << " fuse not support";
     }
   }
-  std::vector<float> ws = param.pw_weight_scale;
+  std::vector<float> ws = fusion_.pw_weight_scale;
   if (ws.size() != 1 && ws.size() != static_cast<size_t>(m)) LOG(FATAL) << "weights scale size must equal to filter size";
   if (ws.size() == 1) ws.resize(m, ws[0]);
-  const float in_scale = param.output_scale, out_scale = param.pw_output_scale;  // dw output scale = pw input scale
-  for (auto& v : ws) v = param.pw_int8_out ? v * in_scale / out_scale : v * in_scale;
+  const float in_scale = param.output_scale, out_scale = fusion_.pw_output_scale;  // dw output scale = pw input scale
+  for (auto& v : ws) v = fusion_.pw_int8_out ? v * in_scale / out_scale : v * in_scale;
   pw_scale_.Resize({m});
   TargetWrapperHip::MemcpySync(pw_scale_.mutable_data<float>(TARGET(kHIP)), ws.data(), m * sizeof(float), IoDirection::HtoD);
-  pw_has_bias_ = param.pw_bias != nullptr;
+  pw_has_bias_ = fusion_.pw_bias != nullptr;
   if (pw_has_bias_) {
-    CHECK_EQ(param.pw_bias->numel(), m) << "bias size must equal to filter number";
+    CHECK_EQ(fusion_.pw_bias->numel(), m) << "bias size must equal to filter number";
     std::vector<float> b(m);
-    TargetCopy(TARGET(kHost), param.pw_bias->target(), b.data(), param.pw_bias->raw_data(), m * sizeof(float));
-    if (param.pw_int8_out)
+    TargetCopy(TARGET(kHost), fusion_.pw_bias->target(), b.data(), fusion_.pw_bias->raw_data(), m * sizeof(float));
+    if (fusion_.pw_int8_out)
       for (auto& v : b) v = v / out_scale;
     pw_bias_.Resize({m});
     TargetWrapperHip::MemcpySync(pw_bias_.mutable_data<float>(TARGET(kHIP)), b.data(), m * sizeof(float), IoDirection::HtoD);
   }
-  if (param.pw_int8_out && pw_desc_.act == PLHIP_ACT_RELU6) alpha = alpha / out_scale;
+  if (fusion_.pw_int8_out && pw_desc_.act == PLHIP_ACT_RELU6) alpha = alpha / out_scale;
   pw_desc_.act_alpha = alpha;
   Tensor staged;
-  const size_t w_bytes = static_cast<size_t>(param.pw_filter->numel());
-  const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(param.pw_filter, &staged, w_bytes));
+  const size_t w_bytes = static_cast<size_t>(fusion_.pw_filter->numel());
+  const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(fusion_.pw_filter, &staged, w_bytes));
   const size_t packed = plhip_conv_packed_weight_bytes(&pw_desc_);
   CHECK_GT(packed, 0UL) << "invalid fused pointwise configuration";
   void* d = pw_weights_.mutable_data(TARGET(kHIP), packed);
@@ -201,7 +201,7 @@ void ConvCompute<Ptype, OutType>::PrepareForRun() {
     ctx.Sync();  // `staged` dies at scope exit
     kernel_func_name_ = plhip_conv_impl_name(&desc_);
   }
-  if (param.pw_filter) PreparePointwise();
+  if (fusion_.pw_filter) PreparePointwise();
   last_shape_ = DDim();
   ReInitWhenNeeded();
 }
@@ -221,10 +221,10 @@ void ConvCompute<Ptype, OutType>::Run() {
     kind = PLHIP_OUT_I8;
   } else {
     // a fused tail may leave the fp32 tensor without consumers (drop_fp32_output): then it is never allocated
-    y = param.drop_fp32_output ? nullptr : param.output->template mutable_data<float>(TARGET(kHIP));
+    y = fusion_.drop_fp32_output ? nullptr : param.output->template mutable_data<float>(TARGET(kHIP));
     kind = PLHIP_OUT_F32;
   }
-  const bool fused_tail = OutType == PRECISION(kFloat) && (param.fuse_residual_connection || param.calib_output != nullptr);
+  const bool fused_tail = OutType == PRECISION(kFloat) && (param.fuse_residual_connection || fusion_.calib_output != nullptr);
   if (fused_tail) {
     CHECK(!is_depthwise_) << "kHIP: the fused conv tail exists on the GEMM-like convs only";
     const float* res = nullptr;
@@ -234,19 +234,19 @@ void ConvCompute<Ptype, OutType>::Run() {
       res = param.residualData->template data<float>();
     }
     int8_t* q = nullptr;
-    if (param.calib_output) {
-      param.calib_output->Resize(param.output->dims());
-      q = param.calib_output->template mutable_data<int8_t>(TARGET(kHIP));
+    if (fusion_.calib_output) {
+      fusion_.calib_output->Resize(param.output->dims());
+      q = fusion_.calib_output->template mutable_data<int8_t>(TARGET(kHIP));
     }
     void* ws = workspace_bytes_ ? ctx.workspace(workspace_bytes_) : nullptr;
     HIP_CALL(ctx.ctx(), plhip_conv2d_int8_fused(ctx.ctx(), &desc_, x, weights_.raw_data(), sc, bi,
-                                                param.drop_fp32_output ? nullptr : static_cast<float*>(y), res,
-                                                param.fuse_residual_relu ? 1 : 0, q, param.calib_scale, ws, workspace_bytes_));
+                                                fusion_.drop_fp32_output ? nullptr : static_cast<float*>(y), res,
+                                                fusion_.fuse_residual_relu ? 1 : 0, q, fusion_.calib_scale, ws, workspace_bytes_));
   } else if (is_depthwise_ && has_pw_) {
-    // `output` is the pointwise conv's tensor (ConvParam::pw_*); y above was allocated as int8: redo it for fp32
-    void* yo = param.pw_int8_out ? static_cast<void*>(param.output->template mutable_data<int8_t>(TARGET(kHIP)))
+    // `output` is the pointwise conv's tensor (HipConvFusion::pw_*); y above was allocated as int8: redo it for fp32
+    void* yo = fusion_.pw_int8_out ? static_cast<void*>(param.output->template mutable_data<int8_t>(TARGET(kHIP)))
                                  : static_cast<void*>(param.output->template mutable_data<float>(TARGET(kHIP)));
-    const plhip_out_kind ko = param.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32;
+    const plhip_out_kind ko = fusion_.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32;
     const float* psc = pw_scale_.data<float>();
     const float* pbi = pw_has_bias_ ? pw_bias_.data<float>() : nullptr;
     if (pw_fused_) {

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "lite/core/kernel.h"
+#include "lite/kernels/hip/conv_fusion.h"
 #include "lite/operators/op_params.h"
 #include "plhip.h"
 
@@ -15,17 +16,19 @@ namespace kernels {
 namespace hip {
 
 template <PrecisionType Ptype, PrecisionType OutType>
-class ConvCompute : public KernelLite<TARGET(kHIP), Ptype> {
+class ConvCompute : public KernelLite<TARGET(kHIP), Ptype>, public HipFusableKernel {
  public:
   using param_t = operators::ConvParam;
   void PrepareForRun() override;
   void ReInitWhenNeeded() override;
   void Run() override;
+  void SetFusion(const HipConvFusion& f) override { fusion_ = f; }  // before the first Launch (conv_fusion.h)
   void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override { ch->kernel_func_name = kernel_func_name_; }
   ~ConvCompute() override = default;
 
  private:
   void BuildDesc();
+  HipConvFusion fusion_;  // default-constructed = the plain conv of the reference
   plhip_conv_desc desc_{};
   bool is_depthwise_{false};
   DDim last_shape_;
@@ -36,7 +39,7 @@ class ConvCompute : public KernelLite<TARGET(kHIP), Ptype> {
   float act_alpha_{0.f};
   size_t workspace_bytes_{0};
   std::string kernel_func_name_{"NotImplForConv"};
-  // fused 1x1 consumer of a depthwise conv (ConvParam::pw_*): its descriptor, packed weights, folded scale / bias; `mid_`
+  // fused 1x1 consumer of a depthwise conv (HipConvFusion::pw_*): its descriptor, packed weights, folded scale / bias; `mid_`
   // holds the depthwise result only when the shape is outside the fused kernel and the two kernels run instead
   void PreparePointwise();
   bool has_pw_{false}, pw_fused_{false}, pw_has_bias_{false};

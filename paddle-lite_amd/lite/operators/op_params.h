@@ -87,26 +87,6 @@ struct ConvParam : ParamBase {
   bool var_length{false};
   std::vector<int> output_size;
   WITH_INT8_CONFIG
-  // ---- kHIP graph-level fusion (not in the reference's struct; set only by lite/api/graph_builder.cc): the fp32_out
-  // kernel can take over the instructions that follow it in the reference program.  residualData (above, the
-  // reference's own field, lite/operators/conv_op.h:102) is the other operand of the fused elementwise_add;
-  // fuse_residual_relu = the add was a fusion_elementwise_add_activation(relu); calib_output = the int8 tensor a following
-  // calib[fp32_to_int8] with scale calib_scale would produce; drop_fp32_output = `output` has no other consumer.
-  bool fuse_residual_relu{false};
-  lite::Tensor* calib_output{nullptr};
-  float calib_scale{1.f};
-  bool drop_fp32_output{false};
-  // ---- kHIP graph-level fusion, second kind (opt-in, GraphBuilder::set_fuse_dwpw): a depthwise_conv2d [int8_out] whose
-  // only consumer is a plain conv2d 1x1 (stride 1, no padding, groups 1) takes that conv over.  `output` is then the
-  // POINTWISE conv's output (int8 or fp32 by pw_int8_out); the depthwise result never exists as a tensor.  The pw_*
-  // fields are the pointwise op's filter / bias / WITH_INT8_CONFIG scales / activation; its input scale is this op's
-  // output_scale.  The kernel runs plhip_dwpw_fused_int8 when the shape is inside the fused path, else the two kernels.
-  lite::Tensor* pw_filter{nullptr};
-  lite::Tensor* pw_bias{nullptr};
-  std::vector<float> pw_weight_scale{};
-  float pw_output_scale{1.f};
-  bool pw_int8_out{true};
-  ActivationParam pw_activation_param;
 };
 
 struct PoolParam : ParamBase {

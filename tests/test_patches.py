@@ -15,6 +15,6 @@ def test_patches_apply_to_the_reference_tree():
     p = subprocess.run([os.path.join(ROOT, "tools", "check_patches.sh")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     out = p.stdout.decode()
     assert p.returncode == 0, out
-    assert "all 4 patches apply" in out
+    assert "all 5 patches apply" in out
     for name in os.listdir(os.path.join(ROOT, "patches")):
         assert name.endswith(".patch") and ("applies: " + name) in out

@@ -10,6 +10,7 @@ T=$(mktemp -d /tmp/khip_patches.XXXXXX)
 trap 'rm -rf "$T"' EXIT
 cd "$T" && git init -q .
 for f in $(grep -h '^diff --git' "$ROOT"/patches/*.patch | sed 's#diff --git a/\([^ ]*\) .*#\1#' | sort -u); do
+  [ -f "$REFERENCE/$f" ] || continue   # a file the patch creates (lite/kernels/hip/CMakeLists.txt ...)
   mkdir -p "$(dirname "$f")" && cp "$REFERENCE/$f" "$f"
 done
 git add -A >/dev/null && git -c user.email=x@y -c user.name=x commit -qm base

@@ -98,6 +98,65 @@ EDITS = {
              "        break;\n      }\n    }\n#endif\n#ifdef LITE_WITH_MLU\n    Env<TARGET(kMLU)>::Init();"),
         ],
     },
+    "0005-runtime-sync-hooks-copysync-kernel-list-and-cmake-for-kHIP.patch": {
+        "lite/core/program.h": [
+            ("  void Sync() const { kernel_->mutable_context()->As<CUDAContext>().Sync(); }\n#endif\n",
+             "  void Sync() const { kernel_->mutable_context()->As<CUDAContext>().Sync(); }\n#endif\n\n"
+             "#ifdef LITE_WITH_HIP\n  // kHIP kernels enqueue on the context's execution stream; like kCUDA an instruction whose inputs were produced on\n"
+             "  // another stream waits for them first (HIPContext::need_sync / Sync: lite/core/context.h)\n"
+             "  bool need_sync_hip() const {\n    return kernel_->target() == TargetType::kHIP && kernel_->mutable_context()->As<HIPContext>().need_sync();\n  }\n"
+             "  void SyncHip() const { kernel_->mutable_context()->As<HIPContext>().Sync(); }\n#endif\n"),
+        ],
+        "lite/core/program.cc": [
+            ("#ifdef LITE_WITH_CUDA\n    if (inst.need_sync()) {\n      inst.Sync();\n    }\n#endif\n    inst.Run();",
+             "#ifdef LITE_WITH_CUDA\n    if (inst.need_sync()) {\n      inst.Sync();\n    }\n#endif\n#ifdef LITE_WITH_HIP\n    if (inst.need_sync_hip()) {\n      inst.SyncHip();\n    }\n#endif\n    inst.Run();"),
+        ],
+        "lite/core/memory.h": [
+            ("#ifdef LITE_WITH_OPENCL\n    case TargetType::kOpenCL:\n      TargetWrapperCL::MemcpySync(dst, src, size, dir);\n      break;\n#endif  // LITE_WITH_OPENCL\n",
+             "#ifdef LITE_WITH_HIP\n    case TARGET(kHIP):\n      TargetWrapper<TARGET(kHIP)>::MemcpySync(dst, src, size, dir);\n      break;\n#endif\n"
+             "#ifdef LITE_WITH_OPENCL\n    case TargetType::kOpenCL:\n      TargetWrapperCL::MemcpySync(dst, src, size, dir);\n      break;\n#endif  // LITE_WITH_OPENCL\n"),
+        ],
+        "lite/api/paddle_use_kernels.h": [
+            ("USE_LITE_KERNEL(depthwise_conv2d, kARM, kInt8, kNCHW, fp32_out);",
+             "USE_LITE_KERNEL(depthwise_conv2d, kARM, kInt8, kNCHW, fp32_out);\n"
+             "#ifdef LITE_WITH_HIP\n"
+             "USE_LITE_KERNEL(conv2d, kHIP, kInt8, kNCHW, int8_out);\nUSE_LITE_KERNEL(conv2d, kHIP, kInt8, kNCHW, fp32_out);\n"
+             "USE_LITE_KERNEL(depthwise_conv2d, kHIP, kInt8, kNCHW, int8_out);\nUSE_LITE_KERNEL(depthwise_conv2d, kHIP, kInt8, kNCHW, fp32_out);\n"
+             "USE_LITE_KERNEL(fc, kHIP, kInt8, kNCHW, int8out);\nUSE_LITE_KERNEL(fc, kHIP, kInt8, kNCHW, fp32out);\n"
+             "USE_LITE_KERNEL(calib, kHIP, kInt8, kNCHW, fp32_to_int8);\nUSE_LITE_KERNEL(calib, kHIP, kInt8, kNCHW, int8_to_fp32);\n"
+             "USE_LITE_KERNEL(io_copy, kHIP, kAny, kAny, host_to_device);\nUSE_LITE_KERNEL(io_copy, kHIP, kAny, kAny, device_to_host);\n"
+             "USE_LITE_KERNEL(pool2d, kHIP, kFloat, kNCHW, def);\nUSE_LITE_KERNEL(pool2d, kHIP, kInt8, kNCHW, def);\n"
+             "USE_LITE_KERNEL(elementwise_add, kHIP, kFloat, kNCHW, def);\nUSE_LITE_KERNEL(fusion_elementwise_add_activation, kHIP, kFloat, kNCHW, def);\n"
+             "USE_LITE_KERNEL(softmax, kHIP, kFloat, kNCHW, def);\n"
+             "#endif  // LITE_WITH_HIP"),
+        ],
+        "lite/kernels/CMakeLists.txt": [
+            ("add_subdirectory(cuda)\n", "add_subdirectory(cuda)\nadd_subdirectory(hip)\n"),
+        ],
+        "lite/backends/CMakeLists.txt": [
+            ("add_subdirectory(cuda)\n", "add_subdirectory(cuda)\nadd_subdirectory(hip)\n"),
+        ],
+    },
+}
+
+
+NEW_FILES = {
+    "0005-runtime-sync-hooks-copysync-kernel-list-and-cmake-for-kHIP.patch": {
+        "lite/kernels/hip/CMakeLists.txt":
+            "if((NOT LITE_ON_MODEL_OPTIMIZE_TOOL) AND (NOT LITE_WITH_PYTHON) AND (NOT LITE_WITH_HIP))\n    return()\nendif()\n\n"
+            "message(STATUS \"compile with lite HIP (gfx950) kernels\")\n\n"
+            "# kernel classes of this repository (paddle-lite_amd/lite/kernels/hip): plain C++ over the C ABI of libplhip.so\n"
+            "add_kernel(conv2d_hip HIP basic SRCS conv_compute.cc DEPS ${lite_kernel_deps} target_wrapper_hip plhip)\n"
+            "add_kernel(fc_compute_hip HIP basic SRCS fc_compute.cc DEPS ${lite_kernel_deps} target_wrapper_hip plhip)\n"
+            "add_kernel(glue_compute_hip HIP basic SRCS glue_compute.cc DEPS ${lite_kernel_deps} target_wrapper_hip plhip)\n",
+        "lite/backends/hip/CMakeLists.txt":
+            "if(NOT LITE_WITH_HIP)\n    return()\nendif()\n\n"
+            "# libplhip.so: the gfx950 kernels + C ABI (include/plhip.h), built by hipcc (paddle-lite_amd/csrc/Makefile)\n"
+            "add_library(plhip SHARED IMPORTED GLOBAL)\n"
+            "set_property(TARGET plhip PROPERTY IMPORTED_LOCATION ${PLHIP_ROOT}/libplhip.so)\n"
+            "include_directories(${PLHIP_ROOT}/../include)\n"
+            "lite_cc_library(target_wrapper_hip SRCS target_wrapper.cc DEPS plhip)\n",
+    },
 }
 
 
@@ -115,7 +174,12 @@ def main():
                 assert dst.count(old) >= 1, "%s: anchor not found:\n%s" % (rel, old)
                 dst = dst.replace(old, new, 1)
             diff = difflib.unified_diff(src.splitlines(True), dst.splitlines(True), "a/" + rel, "b/" + rel, n=3)
-            out.append("diff --git a/%s b/%s\n" % (rel, rel) + "".join(diff))
+            # a last line without a newline (lite/api/paddle_use_kernels.h) needs git's marker
+            out.append("diff --git a/%s b/%s\n" % (rel, rel) + "".join(l if l.endswith("\n") else l + "\n\\ No newline at end of file\n" for l in diff))
+        for rel, text in NEW_FILES.get(pname, {}).items():
+            lines = text.splitlines(True)
+            out.append("diff --git a/%s b/%s\nnew file mode 100644\n--- /dev/null\n+++ b/%s\n@@ -0,0 +1,%d @@\n" % (rel, rel, rel, len(lines)) +
+                       "".join("+" + l for l in lines))
         with open(os.path.join(ROOT, "patches", pname), "w") as f:
             f.write("".join(out))
         print("wrote patches/%s (%d files)" % (pname, len(files)))

@@ -63,18 +63,21 @@ def main():
             def show(label, a):
                 print("  %-40s cyc p10 %7.0f  p50 %7.0f  p90 %7.0f" % ((label,) + tuple(np.percentile(a, [10, 50, 90]))))
 
-            show("entry -> all loads issued", t[:, 3] - t[:, 1])
+            ntt = int(os.environ.get("PLHIP_WIDE_NTT", "0")) or (4 if cin >= 1024 or ho < 14 else 7)
+            deep = ks >= 16
+            tk = ntt if deep else (2 if ntt >= 6 else 1)
+            s1 = min(ks, (ks - 4 + 1) // 2 + 2) if deep else ks
+            show("entry -> first loads issued", t[:, 3] - t[:, 1])
             show("-> K-step 0 landed everywhere", t[:, 4] - t[:, 3])
-            show("-> top of K-step 0 (fragments read)", t[:, 10] - t[:, 4])
-            a0, r = 4, 2
-            s1 = min(ks, (ks - a0 + r - 1) // r + 2)
-            for i in range(s1 - 1):
-                show("phase 1 K-step %d" % i, t[:, 11 + i] - t[:, 10 + i])
-            show("last phase-1 K-step", t[:, 5] - t[:, 10 + s1 - 1])
-            show("whole phase 1 (%d K-steps, all tiles)" % s1, t[:, 5] - t[:, 4])
-            show("phase 2: tile 0 (%d MFMAs, no epilogue)" % (ks - s1), t[:, 6] - t[:, 5])
-            show("phase 2: other tiles + epilogues", t[:, 7] - t[:, 6])
-            show("last tile's epilogue + store drain", t[:, 8] - t[:, 7])
+            for i in range(min(s1, 20) - 1):
+                show("phase 1 (tiles 0-%d) K-step %d" % (tk - 1, i), t[:, 11 + i] - t[:, 10 + i])
+            show("whole phase 1 (%d K-steps, %d tiles K-outer)" % (s1, tk), t[:, 5] - t[:, 4])
+            prev = t[:, 5]
+            for i in range(0 if s1 < ks else tk, ntt):
+                show("phase 2 tile %d: %d MFMAs + slices" % (i, ks - (s1 if i < tk else 0)), t[:, 30 + i] - prev)
+                prev = t[:, 30 + i]
+            show("whole phase 2", t[:, 7] - t[:, 5])
+            show("remaining epilogue + store drain", t[:, 8] - t[:, 7])
             show("wave total", t[:, 8] - t[:, 1])
             clk = (t[:, 8] - t[:, 1]).astype(np.float64) / np.maximum(1, (t[:, 9] - t[:, 0])) / 10.0
             print("  shader clock over wave lifetime: median %.2f GHz" % np.median(clk))
