@@ -688,20 +688,15 @@ static void launch_fused_t(FusedArgs a, hipStream_t s) {
   a.pw.MT = (a.pw.M + WM * 64 - 1) / (WM * 64);        // blocks along the output channels
   const unsigned blocks = (unsigned)((long)a.pw.MT * ((a.pw.NT + 7) / 8 * 8));
   const size_t lds = a.raw_bytes;
-  static size_t attr_lds[2] = {0, 0};  // per instantiation: the largest dynamic LDS size already granted
+  // the attribute is per DEVICE and launches come from several predictor threads: set it on every launch (a host-side
+  // table update; a process-wide "already granted" cache was wrong on a second GPU and racy between threads)
   if (a.stride == 1) {
     auto kfn = fused_dwpw_kernel<WN, WM, OUT, 1>;
-    if (lds > attr_lds[0]) {
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_lds[0] = lds;
-    }
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
   } else {
     auto kfn = fused_dwpw_kernel<WN, WM, OUT, 2>;
-    if (lds > attr_lds[1]) {
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_lds[1] = lds;
-    }
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
   }
 }

@@ -467,11 +467,8 @@ static void launch_tr_cfg2(GemmArgs g, hipStream_t s) {
   const unsigned blocks = (unsigned)((long)g.MT * ((g.NT + 7) / 8 * 8));
   const size_t lds = (size_t)(D + 1) * (BN * 32 + BM * 32) + 8 * TR_STAMP_SLOTS * 8;
   auto kfn = gemm_i8_tr_kernel<WN, WM, OUT, D, IM>;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  // per DEVICE and called from several predictor threads: set on every launch (a process-wide flag was wrong on a second GPU)
+  (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * WN * WM), lds, s, g);
 }
 

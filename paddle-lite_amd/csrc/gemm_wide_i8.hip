@@ -61,7 +61,9 @@ static int wide_env() {  // PLHIP_GEMM_WIDE: 1 (default) on, 0 = second-generati
 int gemm_wide_ntt(const GemmArgs& g) {
   if (!wide_env() || g.im_kw != 0 || g.res || g.y2) return 0;
   if (g.K != g.KS * 32 || (g.KS != 4 && g.KS != 8 && g.KS != 16 && g.KS != 32)) return 0;
-  if (g.M < 256 || g.HWX < 16) return 0;
+  // dense slabs only: the column space IS the output row (an im2col buffer whose rows are padded to a multiple of 4 has
+  // HWX > HWY: its pad columns must not be stored, and the whole-chunk stores here would spill into the next row)
+  if (g.M < 256 || g.HWX < 16 || g.HWX != g.HWY) return 0;
   const int CPI = (g.HWX + 15) >> 4;
   const long chunks = (long)g.NB * CPI;
   if (chunks * 16 >= ((long)1 << 31) - 4096) return 0;

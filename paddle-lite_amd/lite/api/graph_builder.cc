@@ -185,6 +185,10 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
     for (size_t i = 0; i < st.size(); ++i) {
       if (dead[i] || st[i].kind != "op" || ops_[st[i].op].type != "depthwise_conv2d" || !st[i].int8_out || st[i].pw_op >= 0) continue;
       if (uses(st[i].out) != 1) continue;
+      {  // a TRUE depthwise conv only (channel multiplier 1): anything else stays two instructions instead of failing a CHECK later
+        const GraphOp& dwo = ops_[st[i].op];
+        if (dwo.w_dims.size() != 4 || dwo.w_dims[1] != 1 || dwo.w_dims[0] != dwo.conv.groups) continue;
+      }
       int j = -1;
       for (size_t t = 0; t < st.size(); ++t)
         if (!dead[t] && st[t].kind == "op" && !st[t].op_inputs.empty() && st[t].op_inputs[0] == st[i].out) j = static_cast<int>(t);

@@ -223,13 +223,46 @@ std::vector<std::string> HipPredictor::KernelNames() {
   return r;
 }
 
+// Everything a recorded launch graph has baked in: the shape of every variable (grid sizes, strides), the instruction list
+// and the workspace arena (its address is a kernel argument; HipExecState::Workspace frees the arena when it grows).
+size_t HipPredictor::GraphKey() const {
+  size_t h = 1469598103934665603ULL;
+  auto mix = [&h](size_t v) { h = (h ^ v) * 1099511628211ULL; };
+  mix(const_cast<HipPredictor*>(this)->program_.instructions().size());
+  mix(reinterpret_cast<size_t>(state_->workspace_ptr()));
+  mix(state_->workspace_bytes());
+  for (auto& kv : vars_) {
+    const auto d = kv.second->dims();
+    mix(d.size());
+    for (size_t i = 0; i < d.size(); ++i) mix(static_cast<size_t>(d[i]));
+  }
+  return h;
+}
+
 void HipPredictor::RunGraph() {
   TargetWrapperHip::SetDevice(device_);
   plhip_ctx* ctx = state()->ctx();
+  // a feed resized, an instruction added or the arena re-allocated since the recording: the graph is stale (it would read
+  // freed memory / use old shapes): drop it and record again
+  if (graph_exec_ && graph_key_ != GraphKey()) {
+    (void)plhip_graph_destroy(ctx, graph_exec_);
+    graph_exec_ = nullptr;
+  }
   if (!graph_exec_) {
+    // one ordinary run first: PrepareForRun (allocations, weight packing, host syncs) must not happen inside a capture,
+    // and it brings the workspace arena to its final size
+    program_.Run(/*skip_io_copy=*/true);
+    state()->Sync();
     HIP_CALL(ctx, plhip_graph_begin(ctx));
-    program_.Run(/*skip_io_copy=*/true);  // InferShape() + Launch() per instruction, recorded instead of executed
+    try {
+      program_.Run(/*skip_io_copy=*/true);  // InferShape() + Launch() per instruction, recorded instead of executed
+    } catch (...) {
+      void* dead = nullptr;  // never leave the stream in capture mode: end it, discard whatever was recorded, re-throw
+      if (plhip_graph_end(ctx, &dead) == PLHIP_OK && dead) (void)plhip_graph_destroy(ctx, dead);
+      throw;
+    }
     HIP_CALL(ctx, plhip_graph_end(ctx, &graph_exec_));
+    graph_key_ = GraphKey();
   }
   HIP_CALL(ctx, plhip_graph_launch(ctx, graph_exec_));
 }

@@ -90,6 +90,8 @@ class HipPredictor {
   int device_;
   std::shared_ptr<HipExecState> state_;
   void* graph_exec_{nullptr};  // plhip launch graph of the program (RunGraph)
+  size_t graph_key_{0};        // what the recorded graph depends on: shapes of every variable, instruction count, workspace arena
+  size_t GraphKey() const;
   std::map<std::string, std::unique_ptr<Tensor>> vars_;
   std::vector<std::unique_ptr<Tensor>> params_;
   RuntimeProgram program_;

@@ -55,6 +55,8 @@ class HipExecState {
   void* stream() const;
   void Sync() const;
   void* Workspace(size_t bytes);
+  const void* workspace_ptr() const { return ws_; }   // identity of the arena (a recorded launch graph holds its address)
+  size_t workspace_bytes() const { return ws_bytes_; }
   void MemcpySync(void* dst, const void* src, size_t size, IoDirection dir) const;
   void MemcpyAsync(void* dst, const void* src, size_t size, IoDirection dir) const;
 

@@ -13,7 +13,8 @@ struct Reader {
   const std::vector<uint8_t>& b;
   size_t p{0};
   explicit Reader(const std::vector<uint8_t>& bytes) : b(bytes) {}
-  void need(size_t n) { CHECK_LE(p + n, b.size()) << "model container truncated at byte " << p; }
+  // n <= size - p (p <= size always): no wrap-around for sizes read from the file
+  void need(size_t n) { CHECK(p <= b.size() && n <= b.size() - p) << "model container truncated at byte " << p; }
   template <typename T>
   T get() {
     need(sizeof(T));
@@ -37,6 +38,16 @@ const std::string& arg(const std::map<std::string, std::string>& m, const std::s
   return it->second;
 }
 bool is_conv(const std::string& t) { return t == "conv2d" || t == "depthwise_conv2d"; }
+// an fp32 tensor of the model with at least `n` elements (n < 0: exactly one or more), by name: every read of f32() below
+// goes through this, so a malformed model (wrong dtype, too few elements, missing tensor) is an error, not a stray read
+const RawTensor& f32_tensor(const RawModel& m, const std::string& name, int64_t n, const char* what) {
+  const auto it = m.tensors.find(name);
+  CHECK(it != m.tensors.end()) << what << ": tensor " << name << " missing";
+  CHECK_EQ(it->second.dtype, 0) << what << ": tensor " << name << " must be fp32";
+  CHECK(n < 0 ? it->second.numel() >= 1 : it->second.numel() == n) << what << ": tensor " << name << " has " << it->second.numel()
+                                                                    << " elements, expected " << n;
+  return it->second;
+}
 }  // namespace
 
 RawModel ParseContainer(const std::vector<uint8_t>& bytes) {
@@ -52,9 +63,17 @@ RawModel ParseContainer(const std::vector<uint8_t>& bytes) {
     t.dtype = r.get<uint8_t>();
     CHECK(t.dtype == 0 || t.dtype == 1) << "tensor " << name << ": unknown dtype " << t.dtype;
     const int nd = r.get<uint8_t>();
-    for (int d = 0; d < nd; ++d) t.dims.push_back(r.get<int64_t>());
+    CHECK(nd >= 1 && nd <= 6) << "tensor " << name << ": rank " << nd << " outside 1..6";
+    uint64_t numel = 1;
+    for (int d = 0; d < nd; ++d) {
+      const int64_t dim = r.get<int64_t>();
+      CHECK(dim > 0 && dim <= (int64_t(1) << 31)) << "tensor " << name << ": dim " << d << " = " << dim << " is not a positive 32-bit size";
+      CHECK(numel <= (uint64_t(1) << 40) / static_cast<uint64_t>(dim)) << "tensor " << name << ": element count overflows";
+      numel *= static_cast<uint64_t>(dim);
+      t.dims.push_back(dim);
+    }
     const uint64_t nb = r.get<uint64_t>();
-    CHECK_EQ(nb, static_cast<uint64_t>(t.numel()) * (t.dtype == 0 ? 4 : 1)) << "tensor " << name << ": byte count does not match dims";
+    CHECK_EQ(nb, numel * (t.dtype == 0 ? 4 : 1)) << "tensor " << name << ": byte count does not match dims";
     r.need(nb);
     t.data.assign(bytes.begin() + r.p, bytes.begin() + r.p + nb);
     r.p += nb;
@@ -123,9 +142,7 @@ void BuildGraph(RawModel* mp, int batch, GraphBuilder* g) {
     if (o.dead || o.type.rfind("fake_quantize", 0) != 0) continue;
     const int bits = o.iattr.count("bit_length") ? o.iattr["bit_length"] : 8;
     CHECK_EQ(bits, 8) << "only 8-bit quantisation is supported";
-    const auto& st = m.tensors.find(arg(o.out, "OutScale", o));
-    CHECK(st != m.tensors.end()) << "fake_quantize: OutScale tensor missing";
-    const float scale_value = st->second.f32()[0] / range;
+    const float scale_value = f32_tensor(m, arg(o.out, "OutScale", o), -1, "fake_quantize OutScale").f32()[0] / range;
     const std::string x = arg(o.in, "X", o), out = arg(o.out, "Out", o);
     act_scale[x] = scale_value;
     rename_input(out, x);
@@ -150,11 +167,13 @@ void BuildGraph(RawModel* mp, int batch, GraphBuilder* g) {
     const auto cs = consumers(outv);
     if (cs.size() != 1 || ops[cs[0]].type != "fake_dequantize_max_abs") continue;  // not a quantised op
     RawOp& dq = ops[cs[0]];
-    const float max_range = dq.fattr.at("max_range");
+    const float max_range = dq.fattr.count("max_range") ? dq.fattr["max_range"] : 0.f;
     const float whole_weight_scale = static_cast<float>(range * range) / max_range / range;  // :146-147, as written
     const std::string wname = arg(o.in, conv ? "Filter" : "Y", o);
     const auto wt = m.tensors.find(wname);
     CHECK(wt != m.tensors.end() && wt->second.dtype == 0) << o.type << ": fp32 weight tensor " << wname << " missing";
+    CHECK_EQ(wt->second.dims.size(), conv ? 4UL : 2UL) << o.type << ": weight tensor " << wname << " must have rank " << (conv ? 4 : 2);
+    CHECK(dq.fattr.count("max_range") && max_range > 0.f) << "fake_dequantize_max_abs: max_range missing or not positive";
     Q st;
     const int n_scale = static_cast<int>(conv ? wt->second.dims[0] : wt->second.dims[1]);  // :159-174
     st.weight_scale.assign(n_scale, whole_weight_scale);
@@ -176,11 +195,12 @@ void BuildGraph(RawModel* mp, int batch, GraphBuilder* g) {
     const auto cs = consumers(arg(o.out, "Output", o));
     if (cs.size() != 1 || ops[cs[0]].type != "batch_norm") continue;
     RawOp& bn = ops[cs[0]];
-    const RawTensor &sc = m.tensors.at(arg(bn.in, "Scale", bn)), &bi = m.tensors.at(arg(bn.in, "Bias", bn)),
-                    &mean = m.tensors.at(arg(bn.in, "Mean", bn)), &var = m.tensors.at(arg(bn.in, "Variance", bn));
+    const int h = static_cast<int>(st.weight_scale.size());  // = the conv's output channels
+    // "The BN bias's size should be equal to the size of the first dim size of the conv weights" (conv_bn_fuser.cc) - and so
+    // must Scale, Mean and Variance: all four are read h floats deep below
+    const RawTensor &sc = f32_tensor(m, arg(bn.in, "Scale", bn), h, "batch_norm Scale"), &bi = f32_tensor(m, arg(bn.in, "Bias", bn), h, "batch_norm Bias"),
+                    &mean = f32_tensor(m, arg(bn.in, "Mean", bn), h, "batch_norm Mean"), &var = f32_tensor(m, arg(bn.in, "Variance", bn), h, "batch_norm Variance");
     const float eps = bn.fattr.count("epsilon") ? bn.fattr["epsilon"] : 1e-5f;
-    const int h = static_cast<int>(sc.numel());
-    CHECK_EQ(h, static_cast<int>(st.weight_scale.size())) << "The BN bias's size should be equal to the size of the first dim size of the conv weights";
     const int w = static_cast<int>(st.w.size()) / h;
     std::vector<float> bias(bi.f32(), bi.f32() + h);
     for (int i = 0; i < h; ++i) {
@@ -224,6 +244,8 @@ void BuildGraph(RawModel* mp, int batch, GraphBuilder* g) {
     RawOp& add = ops[cs[0]];
     const auto bt = m.tensors.find(arg(add.in, "Y", add));
     if (bt == m.tensors.end()) continue;
+    CHECK_EQ(bt->second.dtype, 0) << "fc bias " << arg(add.in, "Y", add) << " must be fp32";
+    CHECK_EQ(bt->second.numel(), static_cast<int64_t>(kv.second.weight_scale.size())) << "fc bias size must equal the output width";
     kv.second.bias.assign(bt->second.f32(), bt->second.f32() + bt->second.numel());
     kv.second.has_bias = true;
     o.out["Out"] = arg(add.out, "Out", add);
@@ -234,6 +256,7 @@ void BuildGraph(RawModel* mp, int batch, GraphBuilder* g) {
     RawOp& o = ops[i];
     if (o.dead) continue;
     if (o.type == "feed") {
+      CHECK(o.ivattr.count("shape") && o.ivattr["shape"].size() == 3UL) << "feed: attribute shape must be {c, h, w}";
       const auto& d = o.ivattr.at("shape");  // {c, h, w}
       g->Feed(arg(o.out, "Out", o), {batch, d[0], d[1], d[2]}, PRECISION(kFloat));
     } else if (o.type == "fetch") {
@@ -248,6 +271,8 @@ void BuildGraph(RawModel* mp, int batch, GraphBuilder* g) {
       op.w = st.w;
       op.has_bias = st.has_bias;
       op.bias = st.bias;
+      CHECK(o.ivattr.count("strides") && o.ivattr.count("paddings") && o.ivattr.count("dilations") && o.iattr.count("groups"))
+          << o.type << ": strides / paddings / dilations / groups attributes are required";
       op.conv.strides = o.ivattr.at("strides");
       op.conv.paddings = o.ivattr.at("paddings");
       op.conv.dilations = o.ivattr.at("dilations");
@@ -270,6 +295,8 @@ void BuildGraph(RawModel* mp, int batch, GraphBuilder* g) {
       op.conv.weight_scale = st.weight_scale;
     } else if (o.type == "pool2d") {
       GraphOp& op = g->Add("pool2d", {arg(o.in, "X", o)}, arg(o.out, "Out", o));
+      CHECK(o.sattr.count("pooling_type") && o.ivattr.count("ksize") && o.ivattr.count("strides") && o.ivattr.count("paddings"))
+          << "pool2d: pooling_type / ksize / strides / paddings attributes are required";
       op.pooling_type = o.sattr.at("pooling_type");
       op.ksize = o.ivattr.at("ksize");
       op.pool_strides = o.ivattr.at("strides");

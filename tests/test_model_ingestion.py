@@ -90,6 +90,56 @@ def test_loader_rejects_garbage(lite, mf):
         p.close()
 
 
+def test_loader_rejects_malformed_containers(lite, mf):
+    """Sizes and shapes read from the file are never trusted: negative / overflowing dims, a byte count that
+    wraps the bounds check, tensors of the wrong dtype or too short where the fusion passes read h floats, weights of the
+    wrong rank, missing attributes - each is a LiteError, none is an out-of-bounds read."""
+    import struct
+
+    def tensor_rec(name, dtype, dims, nbytes, payload):
+        rec = mf._s(name) + struct.pack("<BB", dtype, len(dims)) + struct.pack("<%dq" % len(dims), *dims) + struct.pack("<Q", nbytes) + payload
+        return rec + b"\0" * ((-(8 + 8 + len(rec))) % 8)
+
+    def blob_with(rec, ntensors=1):
+        return b"PLHIPM01" + struct.pack("<II", ntensors, 0) + rec
+
+    p = lite.Predictor(planner=True)
+    try:
+        for bad, pat in [
+            (blob_with(tensor_rec("t", 0, (-4,), 16, b"\0" * 16)), "positive"),                      # negative dim
+            (blob_with(tensor_rec("t", 0, (1 << 31, 1 << 31, 1 << 31), 0, b"")), "overflow|positive"),  # numel overflow
+            (blob_with(tensor_rec("t", 1, (8,), (1 << 64) - 8, b"\0" * 8)), "byte count"),            # nb wraps p + nb
+            (blob_with(tensor_rec("t", 1, (64,), 64, b"\0" * 8)), "truncated"),                       # payload shorter than nb
+            (blob_with(mf._s("t") + struct.pack("<BB", 0, 0) + struct.pack("<Q", 4) + b"\0" * 4), "rank"),  # rank 0
+            (blob_with(mf._s("t") + struct.pack("<BB", 7, 1)), "dtype"),
+        ]:
+            with pytest.raises(lite.LiteError, match=pat):
+                p.load_model(bad, 1)
+        # semantic malformations of an otherwise valid model
+        tensors, ops = mf.slim_residual_toy()
+        bn = [o for o in ops if o["type"] == "batch_norm"][0]
+        for arg_name, repl, pat in [("Variance", np.zeros(1, np.float32), "elements"), ("Mean", np.zeros(64, np.int8), "fp32")]:
+            t2 = dict(tensors)
+            t2[bn["inputs"][arg_name]] = repl
+            with pytest.raises(lite.LiteError, match=pat):
+                p.load_model(mf.write_container(None, t2, ops), 1)
+        conv = [o for o in ops if o["type"] == "conv2d"][0]
+        t2 = dict(tensors)
+        t2[conv["inputs"]["Filter"]] = tensors[conv["inputs"]["Filter"]].reshape(tensors[conv["inputs"]["Filter"]].shape[0], -1)
+        with pytest.raises(lite.LiteError, match="rank"):
+            p.load_model(mf.write_container(None, t2, ops), 1)
+        ops2 = [dict(o, attrs={k: v for k, v in o.get("attrs", {}).items() if k != "strides"}) if o is conv else o for o in ops]
+        with pytest.raises(lite.LiteError, match="required"):
+            p.load_model(mf.write_container(None, tensors, ops2), 1)
+        qz = [o for o in ops if o["type"].startswith("fake_quantize")][0]
+        t2 = dict(tensors)
+        t2[qz["outputs"]["OutScale"]] = np.zeros(4, np.int8)
+        with pytest.raises(lite.LiteError, match="fp32"):
+            p.load_model(mf.write_container(None, t2, ops), 1)
+    finally:
+        p.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["mobilenet_v1", "residual_toy"])
 def test_loaded_program_equals_in_code_program_and_oracle(lite, wl, mf, plref, which):
