@@ -72,7 +72,7 @@ __device__ __forceinline__ void ds2_store(const DirectS2Args& a, size_t off, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) t[j] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)acc[j], s2, b2), lo2, hi2);
       const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-      pk = ((p + 0x01010101u) >> 1) & 0x7f7f7f7fu;
+      pk = round_half_up4_u8(p);
     } else {
       int q[4];
 #pragma unroll

@@ -17,7 +17,7 @@ __device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, flo
 #pragma unroll
     for (int j = 0; j < 4; ++j) t[j] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)a[j], s2, b2), lo2, hi2);
     const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-    return ((p + 0x01010101u) >> 1) & 0x7f7f7f7fu;
+    return round_half_up4_u8(p);
   }
   int q[4];
 #pragma unroll

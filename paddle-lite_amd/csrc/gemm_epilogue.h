@@ -166,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
             for (int i = 0; i < 4; ++i)
               t[i] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)vv[i], s2, b2), lo2, hi2);  // trunc, 0..254
             const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-            packed = ((p + 0x01010101u) >> 1) & 0x7f7f7f7fu;
+            packed = round_half_up4_u8(p);
           } else {
             int q[4];
 #pragma unroll

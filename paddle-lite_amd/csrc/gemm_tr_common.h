@@ -64,7 +64,7 @@ __device__ __forceinline__ v4i tr_requant_chunk(const v16i& acc, float s2, float
 #pragma unroll
       for (int e = 0; e < 4; ++e) tt[e] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)acc[4 * gq + e], s2, b2), lo2, hi2);
       const uint32_t p = (tt[0] | (tt[1] << 8)) | ((tt[2] | (tt[3] << 8)) << 16);
-      dw[gq] = ((p + 0x01010101u) >> 1) & 0x7f7f7f7fu;
+      dw[gq] = round_half_up4_u8(p);
     } else {
       int qv[4];
 #pragma unroll

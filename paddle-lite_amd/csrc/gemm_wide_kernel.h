@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
         ebytes[r & 3] = (uint32_t)__builtin_amdgcn_fmed3f(y2, lo2, hi2);  // trunc, 0..254
         if constexpr ((r & 3) == 3) {
           const uint32_t p = (ebytes[0] | (ebytes[1] << 8)) | ((ebytes[2] | (ebytes[3] << 8)) << 16);
-          edw[r >> 2] = ((p + 0x01010101u) >> 1) & 0x7f7f7f7fu;
+          edw[r >> 2] = round_half_up4_u8(p);
         }
       } else {
         y2 = y2 > 0.f ? y2 : leak * y2;

@@ -41,6 +41,15 @@ __device__ __forceinline__ int round_sat_i8(float y) {
   return (t + 1 + (t >> 31)) >> 1;
 }
 
+// q = (t + 1) >> 1 on four packed bytes t in 0..254 (the relu / relu6 requantisation on doubled values): v_lerp_u8 computes
+// (a + b + (c & 1)) >> 1 per byte without carries between bytes: ONE instruction for add, shift and mask (semantics
+// checked on the device, tools/probe_cvt_pk_u8.hip; every VALU instruction costs the SIMD 4 cycles, and the
+// requantisation is most of what these kernels issue).  v_cvt_pk_u8_f32 cannot replace the float -> byte conversion:
+// it rounds to nearest EVEN (0.5 -> 0, 2.5 -> 2), the reference rounds half away from zero.
+__device__ __forceinline__ uint32_t round_half_up4_u8(uint32_t packed_doubled) {
+  return __builtin_amdgcn_lerp(packed_doubled, 0u, 0x01010101u);
+}
+
 __device__ __forceinline__ uint32_t pack4_i8(int q0, int q1, int q2, int q3) {
   // low byte of each int32 -> one dword, little endian
   uint32_t lo = __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);  // [q0.b0, q1.b0, 0, 0]
