@@ -199,6 +199,54 @@ def test_mobilenet_v1_int8_program_at_batch_128(lite, wl, plref):
         p.close()
 
 
+def _big_batch_check(lite, wl, plref, net, B, seed, fuse, mid):
+    """The program at its BENCHMARK batch (grid sizes, XCD tile maps, multi-round wide tiles, phase-split copies of that
+    size): the first two images must reproduce the batch-2 run bit for bit (that run is compared with the oracle variable
+    by variable in the tests above), and one image from the middle of the batch is compared with the oracle directly."""
+    rng = np.random.default_rng(seed)
+    c, h, w = net["input_shape"]
+    img = rng.uniform(-1, 1, (B, c, h, w)).astype(np.float32)
+    ref_mid = graph_oracle.forward(plref, net, img[mid:mid + 1], via_gemm=True)
+    small, out = _run_graph(lite, wl, net, img[:2], fuse=fuse)
+    try:
+        big, out_b = _run_graph(lite, wl, net, img, fuse=fuse)
+        try:
+            assert out == out_b
+            n_i8 = n_f32 = 0
+            for name, want in ref_mid.items():
+                try:
+                    s_ = small.get_var(name, want.dtype)
+                except Exception:  # noqa: BLE001  (a variable the fused program does not materialise)
+                    continue
+                g_ = big.get_var(name, want.dtype, max_bytes=int(want.nbytes) * B + 64)
+                assert g_.shape[0] == B and s_.shape[0] == 2, name
+                if want.dtype == np.int8:
+                    assert np.array_equal(g_[:2], s_), "%s: batch-%d prefix differs from the batch-2 run" % (name, B)
+                    assert np.array_equal(g_[mid:mid + 1], want), "%s: image %d differs from the oracle" % (name, mid)
+                    n_i8 += 1
+                else:
+                    np.testing.assert_array_equal(g_[:2], s_, err_msg=name)  # same kernels, same order: identical
+                    np.testing.assert_allclose(g_[mid:mid + 1], want, rtol=1e-4 if name == out else 1e-5, atol=1e-5, err_msg=name)
+                    n_f32 += 1
+            return n_i8, n_f32
+        finally:
+            big.close()
+    finally:
+        small.close()
+
+
+def test_resnet50_at_the_benchmark_batch_256(lite, wl, plref):
+    """BASELINE config C4 at batch 256 (what bench.py --config c4 times), default (fused) program."""
+    n_i8, n_f32 = _big_batch_check(lite, wl, plref, wl.resnet50_net(), 256, 320, fuse=True, mid=137)
+    assert n_i8 >= 30 and n_f32 >= 2
+
+
+def test_mobilenet_v2_at_the_benchmark_batch_1024(lite, wl, plref):
+    """BASELINE config C5's global batch on one GPU (bench.py --config c5 on one rank times exactly this)."""
+    n_i8, n_f32 = _big_batch_check(lite, wl, plref, wl.mobilenet_v2_net(), 1024, 321, fuse=True, mid=611)
+    assert n_i8 >= 30 and n_f32 >= 2
+
+
 def test_pointwise_7x7_rows_at_the_end_of_an_allocation(gpu_ctx, plref, pkg):
     """HW = 49 rows are not a multiple of 4 bytes: the ring kernel's END-aligned 16-byte pieces must use the true row
     length (round 1 passed the length rounded up to 4 and read 3 bytes past the last row).  pw13's shape at batch 128:
