@@ -95,12 +95,18 @@ def check_kernel(name, lines):
 
 
 def main():
-    with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "gemm.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm",
-                               "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", "-o", asm, SRC],
-                              stderr=subprocess.DEVNULL)
-        text = open(asm).read().splitlines()
+    kept = None
+    if "--asm-dir" in sys.argv:  # the ISA csrc/Makefile keeps from the real build (-save-temps=obj): no second compile
+        kept = os.path.join(sys.argv[sys.argv.index("--asm-dir") + 1], "gemm_i8-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if kept and os.path.exists(kept):
+        text = open(kept).read().splitlines()
+    else:
+        with tempfile.TemporaryDirectory() as td:
+            asm = os.path.join(td, "gemm.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm",
+                                   "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", "-o", asm, SRC],
+                                  stderr=subprocess.DEVNULL)
+            text = open(asm).read().splitlines()
     kern = re.compile(r"^(_ZN5plhip18gemm_i8_dma_kernelILi(\d)ELi(\d)ELb([01])ELb([01])ELi4ELi(\d+)EEEvNS_8GemmArgsE):")
     cur, body, total_err, nk = None, [], [], 0
     for i, line in enumerate(text, 1):
@@ -114,8 +120,9 @@ def main():
                 if cur[1] > 0:
                     nload, nmfma, errs = check_kernel(cur[0], body)
                     nk += 1
-                    print("%-70s NG=%d  %3d fragment loads, %4d MFMAs: %s" % (cur[0][:70], cur[1], nload, nmfma,
-                                                                            "clean" if not errs else "%d PROBLEMS" % len(errs)))
+                    if errs or "--quiet" not in sys.argv:
+                        print("%-70s NG=%d  %3d fragment loads, %4d MFMAs: %s" % (cur[0][:70], cur[1], nload, nmfma,
+                                                                                "clean" if not errs else "%d PROBLEMS" % len(errs)))
                     total_err += errs
                 cur = None
     for e in total_err[:40]:

@@ -94,13 +94,26 @@ def check_kernel(name, lines, load_ops):
     return nload, len(mfmas), errs
 
 
+def kept_asm(src):
+    """--asm-dir DIR: the ISA csrc/Makefile keeps from the real build (-save-temps=obj), so that the check costs no compile"""
+    if "--asm-dir" in sys.argv:
+        p = os.path.join(sys.argv[sys.argv.index("--asm-dir") + 1], src[:-4] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        if os.path.exists(p):
+            return p
+    return None
+
+
 def run(src, kernel_re, load_ops):
-    with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm",
-                               "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, src)],
-                              stderr=subprocess.DEVNULL)
-        text = open(asm).read().splitlines()
+    kept = kept_asm(src)
+    if kept:
+        text = open(kept).read().splitlines()
+    else:
+        with tempfile.TemporaryDirectory() as td:
+            asm = os.path.join(td, "k.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm",
+                                   "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, src)],
+                                  stderr=subprocess.DEVNULL)
+            text = open(asm).read().splitlines()
     kern = re.compile(kernel_re)
     cur, body, total, nk = None, [], [], 0
     for i, line in enumerate(text, 1):
@@ -113,7 +126,8 @@ def run(src, kernel_re, load_ops):
             if "s_endpgm" in line:
                 nl, nm, errs = check_kernel(cur, body, load_ops)
                 nk += 1
-                print("%-72s %3d asm operand loads, %4d MFMAs: %s" % (cur[:72], nl, nm, "clean" if not errs else "%d PROBLEMS" % len(errs)))
+                if errs or "--quiet" not in sys.argv:
+                    print("%-72s %3d asm operand loads, %4d MFMAs: %s" % (cur[:72], nl, nm, "clean" if not errs else "%d PROBLEMS" % len(errs)))
                 total += errs
                 cur = None
     return nk, total
