@@ -608,8 +608,8 @@ def main():
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script: FETCH_SIZE x2 per the gfx950 correction
         # + WRITE_SIZE); a file, not a live counter -> named in traffic_source, null when absent for this config
         traffic, tsrc = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.config == "c3" and rows == 128:
+        tpath = os.path.join(ROOT, "profiles", {"c3": "pmc_traffic.json", "c4": "pmc_traffic_c4.json"}.get(args.config, "none"))
+        if os.path.exists(tpath) and rows == cfg["batch"]:
             try:
                 tj = json.load(open(tpath))
                 t_ = tj.get(dom)

@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256, GD_D <= 4 ? 2 : 1) void gemm_i8_dma_kernel(Gem
 //     4-deep register ring (their only vector-memory traffic, so the in-order vmcnt never couples to anything slow),
 //     8 MFMAs per K-step;
 //   * one s_barrier per K-step hands fragment buffer (ks+1)&1 to the consumers and buffer ks&1 back to the producers.
+#ifdef PLHIP_EXPERIMENTS  // make EXPERIMENTS=1 (PLHIP_GEMM_VARIANT=5): slower than the ring kernel, kept as a record
 #define WS_D 5   // K-steps a producer keeps in flight
 #define WS_NS 6  // slots of its private raw ring
 
@@ -802,6 +803,8 @@ __global__ __launch_bounds__(384, 2) void gemm_i8_ws_kernel(GemmArgs g) {
   }
 }
 
+#endif  // PLHIP_EXPERIMENTS
+
 // ---- weight pre-pack: [G][Mg][Kg] row-major (OIHW flattened) -> [G][MT32][KS][64 lanes][16 B] ----
 // lane (r = lane&31, h = lane>>5), byte j  <-  W[g][mt32*32 + r][ks*32 + 16h + j]   (0 outside).
 __global__ void pack_weights_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp, int G, int Mg, int Kg,
@@ -889,6 +892,7 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
   GemmArgs g = g_in;
   const bool mfull = g.M % (32 * MA) == 0;
   const int var = gemm_variant();
+#ifdef PLHIP_EXPERIMENTS
   const bool use_ws = MA == 2 && aligned && var == 5 && g.im_kw == 0;  // experiment, opt-in: slower than the ring
   if (use_ws) {
     const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
@@ -900,6 +904,7 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
       hipLaunchKernelGGL((gemm_i8_ws_kernel<OUT, false, false>), dim3(blocks), dim3(384), 0, s, g);
     return;
   }
+#endif
   // (32-row wave tiles with a short K -- e.g. 128->128 at 56x56 -- run faster on the register-staged kernel: 24.8 vs 26.6 us)
   const bool use_dma = g.im_kw > 0 ||  // the implicit-GEMM route exists only in the ring kernel (conv_geom checked the shape)
                        (g.HWX >= 16 && g.KS >= 4 && (var == 3 || (var == 0 && g.MT >= 4 && (MA == 2 || g.KS >= 8))));

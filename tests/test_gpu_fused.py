@@ -59,6 +59,8 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         ran.append(_case(gpu_ctx, capi, plref, rng, n, c, h, w, st, pad, m, da, pa, i8, pw_alpha=(6.0 if pa == 2 else 0.3),
                          dw_alpha=(6.0 if da == 2 else 0.0)))
     print("fused cases run:", ran)
+    if sum(ran) == 0:
+        pytest.skip("libplhip.so built without the fused dw -> pw experiment (make -C paddle-lite_amd/csrc EXPERIMENTS=1)")
     assert sum(ran) >= 6, ran
 
 
@@ -70,3 +72,4 @@ def test_fused_unsupported_shapes_are_reported(gpu_ctx, pkg):
     st = gpu_ctx.L.plhip_dwpw_fused_int8(gpu_ctx.h, C.byref(d), z, z, z, None, 8, z, z, None, 0, 0.0, z, capi.OUT_I8)
     assert st == -3
     gpu_ctx.free(z)
+    # (the default library carries no fused kernel at all: every shape is "unsupported")

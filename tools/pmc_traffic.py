@@ -28,6 +28,8 @@ def family(name):
         return "depthwise3x3"
     if "conv3x3s2" in name:
         return "stem_conv"
+    if "gemm_i8_tr_kernel" in name:
+        return "conv_implicit_gemm"  # dense k x k convs (the implicit-GEMM route); 1x1 convs never use this kernel by default
     if "gemm_i8" in name:
         return "pointwise1x1"
     if "calib_f32_to_i8" in name:

@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = os.path.join(ROOT, "gpurun_out", "evidence")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def cp(src, dst):
@@ -27,10 +27,10 @@ cp("opbench.txt", "opbench.txt")
 cp("layer_table.txt", "layer_table.txt")
 cp("bench.json", "bench.json")
 cp("bench_inflight1.json", "bench_inflight1.json")
-cp("gemm_timeline_pw8.txt", "gemm_timeline_pw8.txt")
 for f in ("bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.json", "layer_table_c4.txt", "layer_table_c5.txt",
-          "opbench_b256.txt", "opbench_fused.txt", "fused_timeline_dw8.txt", "gemm_tr_timeline_pw8.txt", "c2bench.txt",
-          "pmc_sq_c3.csv", "pmc_sq_c4.csv", "fused_concurrency.txt"):
+          "opbench_b256.txt", "opbench_pw_wide_off.txt", "wide_timeline_pw8.txt", "wide_timeline_pw6.txt", "wide_timeline_pw13.txt",
+          "wide_timeline_pw14.txt", "gemm_timeline_pw8_ring.txt", "c2bench.txt", "pmc_sq_c3.csv", "pmc_sq_c4.csv",
+          "bench_driver_form.json"):
     if os.path.exists(os.path.join(E, f)):
         cp(f, f)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -47,14 +47,16 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             o.write('"%s",%d,%.1f,%.1f\n' % (k, n, v, v / n))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(E, "fetch"),
                        os.path.join(E, "write"), os.path.join(P, "pmc_traffic.json")], stdout=subprocess.DEVNULL)
+if os.path.isdir(os.path.join(E, "fetch_c4")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(E, "fetch_c4"),
+                           os.path.join(E, "write_c4"), os.path.join(P, "pmc_traffic_c4.json")], stdout=subprocess.DEVNULL)
 
 
 def g(f):
     return json.loads(open(os.path.join(E, f)).read().strip().splitlines()[-1])
 
 
-for f in ("bench.json", "bench_inflight1.json", "bench_inflight2.json", "bench_inflight4.json", "bench_c4.json", "bench_c5.json",
-          "bench_c2.json", "bench_force_dist.json"):
+for f in ("bench.json", "bench_driver_form.json", "bench_inflight1.json", "bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.json"):
     d = g(f)
     print("%-24s %9.1f img/s  %.4f ms/step  roofline.frac %.4f" % (f, d["value"], d["ms_per_step"], d["roofline"]["frac"]))
 print(open(os.path.join(P, "%s_final_opbench.txt" % tag)).read().splitlines()[-1])
