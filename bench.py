@@ -362,290 +362,314 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("only %d of %d ranks joined" % (dist.get_world_size(), args.gpus))
 
-    # ---- work split ----
-    scaling = args.scaling or cfg.get("scaling", "weak")
-    per_gpu = args.batch or cfg["batch"]
-    if scaling == "strong":
-        global_batch = args.global_batch or cfg.get("global_batch", per_gpu)
-    else:
-        global_batch = per_gpu * world
-    lo, hi = sharding.shard_range(global_batch, rank, world)
-    rows = hi - lo
-    max_rows = max(sharding.shard_range(global_batch, r, world)[1] - sharding.shard_range(global_batch, r, world)[0]
-                   for r in range(world))
-    if rows < 1:
-        raise SystemExit("global batch %d leaves rank %d without work" % (global_batch, rank))
-
-    # ---- network: rank 0 generates, RCCL broadcast over xGMI, every rank builds its predictors from the bytes ----
-    net = build_net(wl, cfg, args.res) if rank == 0 else None
-    net = sharding.broadcast_net(net, dist, dev, rank, world, force=use_dist)
-    classes = net["shapes"][net["output"]][0] * net["shapes"][net["output"]][1] * net["shapes"][net["output"]][2]
-
-    # ---- ONE global batch, generated on rank 0 and scattered (device to device over xGMI), resident before timing ----
-    c, h, w = net["input_shape"]
-    images = None
-    if rank == 0 and not dry:
-        rng = np.random.default_rng(1000)
-        if cfg["model"] == "conv":
-            images = rng.integers(-127, 128, (global_batch, c, h, w)).astype(np.int8)
+    def run_case(scaling, global_batch_arg, per_gpu_arg, details):
+        """One timed case: build the predictors for this split, warm up, time `windows` x `steps` steps, tear down.
+        details: also the serial rate, the per-kernel table / roofline, the oracle self-check and the CPU baseline (headline
+        case only; the extra strong-scaling point of a multi-GPU run carries its rate alone)."""
+        # ---- work split ----
+        per_gpu = per_gpu_arg or cfg["batch"]
+        if scaling == "strong":
+            global_batch = global_batch_arg or cfg.get("global_batch", per_gpu)
         else:
-            images = rng.uniform(-1, 1, (global_batch, c, h, w)).astype(np.float32)
-    check_images = images[:2].copy() if images is not None else None  # rank 0's shard starts at image 0
-    if dry:
-        image = None
-    elif cfg["model"] == "conv":
-        image = images
-    else:
-        image = sharding.scatter_batch(images, global_batch, (c, h, w), dist, dev, rank, world, force=use_dist)
+            global_batch = per_gpu * world
+        lo, hi = sharding.shard_range(global_batch, rank, world)
+        rows = hi - lo
+        max_rows = max(sharding.shard_range(global_batch, r, world)[1] - sharding.shard_range(global_batch, r, world)[0]
+                       for r in range(world))
+        if rows < 1:
+            raise SystemExit("global batch %d leaves rank %d without work" % (global_batch, rank))
+
+        # ---- network: rank 0 generates, RCCL broadcast over xGMI, every rank builds its predictors from the bytes ----
+        net = build_net(wl, cfg, args.res) if rank == 0 else None
+        net = sharding.broadcast_net(net, dist, dev, rank, world, force=use_dist)
+        classes = net["shapes"][net["output"]][0] * net["shapes"][net["output"]][1] * net["shapes"][net["output"]][2]
+
+        # ---- ONE global batch, generated on rank 0 and scattered (device to device over xGMI), resident before timing ----
+        c, h, w = net["input_shape"]
         images = None
+        if rank == 0 and not dry:
+            rng = np.random.default_rng(1000)
+            if cfg["model"] == "conv":
+                images = rng.integers(-127, 128, (global_batch, c, h, w)).astype(np.int8)
+            else:
+                images = rng.uniform(-1, 1, (global_batch, c, h, w)).astype(np.float32)
+        check_images = images[:2].copy() if images is not None else None  # rank 0's shard starts at image 0
+        if dry:
+            image = None
+        elif cfg["model"] == "conv":
+            image = images
+        else:
+            image = sharding.scatter_batch(images, global_batch, (c, h, w), dist, dev, rank, world, force=use_dist)
+            images = None
 
-    P = max(1, args.inflight)
-    out_bytes = rows * classes * (1 if cfg["model"] == "conv" else 4)
-    engines, errs = [None] * P, []
+        P = max(1, args.inflight)
+        out_bytes = rows * classes * (1 if cfg["model"] == "conv" else 4)
+        engines, errs = [None] * P, []
 
-    # ---- per-step result gather (N > 1): DEPTH staging slots; step s uses slot s % DEPTH.  The predictor thread stages
-    # its probabilities behind the slot's previous collective (event) and tells the coordinator (queue, no reply needed);
-    # the coordinator (this thread) issues the collectives in step order on a stream that carries no compute, so every
-    # rank issues them in the same order and the all_gather of step s overlaps the kernels of the following steps. ----
-    DEPTH = 2 * P + 2
-    if use_dist:
-        local = [torch.zeros((max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
-        gathered = [torch.empty((world * max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
-        slot_free = [threading.Semaphore(1) for _ in range(DEPTH)]
-        slot_event = [None] * DEPTH
-        pending = [None] * DEPTH
-    coord_stream = None if dry else torch.cuda.Stream(dev)
-
-    class Flight(threading.Thread):
-        """Predictor i runs the steps i, i+P, i+2P, ... as whole steps on its own stream."""
-
-        def __init__(self, i):
-            super().__init__(daemon=True)
-            self.i, self.cmd, self.done = i, threading.Semaphore(0), threading.Semaphore(0)
-            self.doneq = queue.Queue()
-            self.n, self.base, self.alive, self.err = 0, 0, True, None
-
-        def run(self):
-            try:
-                if dry:
-                    engines[self.i] = DryEngine(torch, lo, rows, classes)
-                else:
-                    torch.cuda.set_device(local_rank)
-                    engines[self.i] = HipEngine(torch, lite, wl, local_rank, dev, net, rows, image, cfg)
-            except Exception as e:  # noqa: BLE001
-                self.err = e
-            self.done.release()
-            while True:
-                self.cmd.acquire()
-                if not self.alive:
-                    break
-                try:
-                    e = engines[self.i]
-                    for s_ in range(self.i, self.n, P):
-                        e.run()
-                        if use_dist:
-                            b = (self.base + s_) % DEPTH
-                            slot_free[b].acquire()      # host: the collective that last read this slot has been ISSUED
-                            e.wait_event(slot_event[b])  # device: ... and will have FINISHED before the copy below
-                            e.stage(local[b], out_bytes)
-                            self.doneq.put(e.record())
-                except Exception as ex:  # noqa: BLE001
-                    self.err = ex
-                self.done.release()
-
-    flights = [Flight(i) for i in range(P)]
-    for f_ in flights:
-        f_.start()
-    for f_ in flights:
-        f_.done.acquire()
-        if f_.err:
-            raise f_.err
-    step_base = [0]
-    last_gather = [None]
-
-    def run_steps(n):
-        """n steps in total, dealt round-robin over the P predictors; this thread only coordinates."""
-        for f_ in flights:
-            f_.n, f_.base = n, step_base[0]
-            f_.cmd.release()
+        # ---- per-step result gather (N > 1): DEPTH staging slots; step s uses slot s % DEPTH.  The predictor thread stages
+        # its probabilities behind the slot's previous collective (event) and tells the coordinator (queue, no reply needed);
+        # the coordinator (this thread) issues the collectives in step order on a stream that carries no compute, so every
+        # rank issues them in the same order and the all_gather of step s overlaps the kernels of the following steps. ----
+        DEPTH = 2 * P + 2
         if use_dist:
-            for s_ in range(n):
-                f_ = flights[s_ % P]
+            local = [torch.zeros((max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
+            gathered = [torch.empty((world * max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
+            slot_free = [threading.Semaphore(1) for _ in range(DEPTH)]
+            slot_event = [None] * DEPTH
+            pending = [None] * DEPTH
+        coord_stream = None if dry else torch.cuda.Stream(dev)
+
+        class Flight(threading.Thread):
+            """Predictor i runs the steps i, i+P, i+2P, ... as whole steps on its own stream."""
+
+            def __init__(self, i):
+                super().__init__(daemon=True)
+                self.i, self.cmd, self.done = i, threading.Semaphore(0), threading.Semaphore(0)
+                self.doneq = queue.Queue()
+                self.n, self.base, self.alive, self.err = 0, 0, True, None
+
+            def run(self):
+                try:
+                    if dry:
+                        engines[self.i] = DryEngine(torch, lo, rows, classes)
+                    else:
+                        torch.cuda.set_device(local_rank)
+                        engines[self.i] = HipEngine(torch, lite, wl, local_rank, dev, net, rows, image, cfg)
+                except Exception as e:  # noqa: BLE001
+                    self.err = e
+                self.done.release()
                 while True:
-                    try:
-                        ev = f_.doneq.get(timeout=1.0)
+                    self.cmd.acquire()
+                    if not self.alive:
                         break
-                    except queue.Empty:
-                        if f_.err:
-                            raise f_.err
-                b = (step_base[0] + s_) % DEPTH
-                if dry:
-                    pending[b] = dist.all_gather_into_tensor(gathered[b], local[b], async_op=True)
-                    pending[b].wait()
-                else:
-                    with torch.cuda.stream(coord_stream):
-                        coord_stream.wait_event(ev)
-                        pending[b] = dist.all_gather_into_tensor(gathered[b], local[b], async_op=True)
-                        pending[b].wait()  # stream-level: coord_stream (no compute on it) is ordered behind the collective
-                        fe = torch.cuda.Event()
-                        fe.record(coord_stream)
-                    slot_event[b] = fe
-                last_gather[0] = gathered[b]
-                slot_free[b].release()
+                    try:
+                        e = engines[self.i]
+                        for s_ in range(self.i, self.n, P):
+                            e.run()
+                            if use_dist:
+                                b = (self.base + s_) % DEPTH
+                                slot_free[b].acquire()      # host: the collective that last read this slot has been ISSUED
+                                e.wait_event(slot_event[b])  # device: ... and will have FINISHED before the copy below
+                                e.stage(local[b], out_bytes)
+                                self.doneq.put(e.record())
+                    except Exception as ex:  # noqa: BLE001
+                        self.err = ex
+                    self.done.release()
+
+        flights = [Flight(i) for i in range(P)]
+        for f_ in flights:
+            f_.start()
         for f_ in flights:
             f_.done.acquire()
             if f_.err:
                 raise f_.err
-        step_base[0] += n
-        if use_dist and not dry:
-            coord_stream.synchronize()  # every step's result is complete inside the timed region
+        step_base = [0]
+        last_gather = [None]
 
-    def sync_all():
-        if not dry:
+        def run_steps(n):
+            """n steps in total, dealt round-robin over the P predictors; this thread only coordinates."""
+            for f_ in flights:
+                f_.n, f_.base = n, step_base[0]
+                f_.cmd.release()
+            if use_dist:
+                for s_ in range(n):
+                    f_ = flights[s_ % P]
+                    while True:
+                        try:
+                            ev = f_.doneq.get(timeout=1.0)
+                            break
+                        except queue.Empty:
+                            if f_.err:
+                                raise f_.err
+                    b = (step_base[0] + s_) % DEPTH
+                    if dry:
+                        pending[b] = dist.all_gather_into_tensor(gathered[b], local[b], async_op=True)
+                        pending[b].wait()
+                    else:
+                        with torch.cuda.stream(coord_stream):
+                            coord_stream.wait_event(ev)
+                            pending[b] = dist.all_gather_into_tensor(gathered[b], local[b], async_op=True)
+                            pending[b].wait()  # stream-level: coord_stream (no compute on it) is ordered behind the collective
+                            fe = torch.cuda.Event()
+                            fe.record(coord_stream)
+                        slot_event[b] = fe
+                    last_gather[0] = gathered[b]
+                    slot_free[b].release()
+            for f_ in flights:
+                f_.done.acquire()
+                if f_.err:
+                    raise f_.err
+            step_base[0] += n
+            if use_dist and not dry:
+                coord_stream.synchronize()  # every step's result is complete inside the timed region
+
+        def sync_all():
+            if not dry:
+                torch.cuda.synchronize(dev)
+            if use_dist:
+                dist.barrier()
+            if not dry:
+                torch.cuda.synchronize(dev)
+
+        run_steps(args.warmup)
+        # EXACTLY args.steps steps per timed window, barrier + synchronize on both sides (the contract); the window is repeated
+        # back to back and the MEDIAN window is reported: a single 20-step window is ~9 ms here and moved the figure by 3-7 %
+        # from run to run.  min / median / max over the windows are in the line.
+        wins = []
+        for _ in range(max(1, args.windows)):
+            sync_all()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            sync_all()
+            el = time.perf_counter() - t0
+            if use_dist:
+                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            wins.append(el)
+        elapsed = float(np.median(wins))
+
+        # ---- outside the timed region: the gathered result of the last step is complete and in rank-major image order ----
+        if use_dist and last_gather[0] is not None:
+            g_ = last_gather[0].float().cpu().numpy().reshape(world, max_rows, classes)
+            for r in range(world):
+                l_, h_ = sharding.shard_range(global_batch, r, world)
+                blk = g_[r, :h_ - l_]
+                if dry:
+                    assert np.array_equal(blk[:, 0], np.arange(l_, h_, dtype=np.float32)), "gathered rows out of order"
+                else:
+                    assert np.all(np.isfinite(blk)) and np.allclose(blk.sum(-1), 1.0, rtol=1e-3), "gathered probabilities are not distributions"
+
+        eng0 = engines[0]
+        pred = None if dry else eng0.pred
+        serial, roof, fam_out = None, None, {}
+        if rank == 0 and not dry and details:
+            stream = eng0.stream
+            # ---- informational: the same steps strictly serial on one stream (what one predictor alone delivers) ----
+            if P > 1:
+                for _ in range(3):
+                    eng0.run()
+                torch.cuda.synchronize(dev)
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    eng0.run()
+                torch.cuda.synchronize(dev)
+                es = time.perf_counter() - ts
+                serial = {"value": round(rows * args.steps / es, 1), "unit": "img/s", "ms_per_step": round(1e3 * es / args.steps, 4),
+                          "note": "one predictor, one stream, steps back to back (this GPU's shard only): a step LATENCY"}
+
+            # ---- per-launch kernel time, live, HIP events on the launch stream.  One event pair brackets INNER back-to-back
+            # launches of the same instruction: a pair around nothing already reads ~4.7 us on this stack, so a pair per
+            # launch overstated every kernel by ~3 us against rocprofv3's averages; with 4 launches per pair the residue is < 1 us.
+            names = pred.kernel_names()
+            body = [i for i, n_ in enumerate(names) if not n_.startswith("io_copy")]
+            reps, INNER = 5, 4
+            with torch.cuda.stream(stream):
+                ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in body] for _ in range(reps)]
+                for r in range(reps):
+                    for j, i in enumerate(body):
+                        ev[r][j][0].record(stream)
+                        for _ in range(INNER):
+                            pred.run_instruction(i)
+                        ev[r][j][1].record(stream)
             torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-        if not dry:
-            torch.cuda.synchronize(dev)
-
-    run_steps(args.warmup)
-    # EXACTLY args.steps steps per timed window, barrier + synchronize on both sides (the contract); the window is repeated
-    # back to back and the MEDIAN window is reported: a single 20-step window is ~9 ms here and moved the figure by 3-7 %
-    # from run to run.  min / median / max over the windows are in the line.
-    wins = []
-    for _ in range(max(1, args.windows)):
-        sync_all()
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        sync_all()
-        el = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        wins.append(el)
-    elapsed = float(np.median(wins))
-
-    # ---- outside the timed region: the gathered result of the last step is complete and in rank-major image order ----
-    if use_dist and last_gather[0] is not None:
-        g_ = last_gather[0].float().cpu().numpy().reshape(world, max_rows, classes)
-        for r in range(world):
-            l_, h_ = sharding.shard_range(global_batch, r, world)
-            blk = g_[r, :h_ - l_]
-            if dry:
-                assert np.array_equal(blk[:, 0], np.arange(l_, h_, dtype=np.float32)), "gathered rows out of order"
+            per_inst = {i: float(np.median([ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(reps)])) / INNER
+                        for j, i in enumerate(body)}
+            if cfg["model"] == "conv":
+                o = net["ops"][0]
+                cout, cin, k, _ = o["w"].shape
+                costs = [dict(name="image", family="io_copy", ops=0, bytes=0),
+                         dict(name="y", family="conv3x3", ops=2 * rows * cout * 56 * 56 * cin * k * k,
+                              bytes=rows * (cin * 56 * 56 + cout * 56 * 56) + o["w"].size)]
             else:
-                assert np.all(np.isfinite(blk)) and np.allclose(blk.sum(-1), 1.0, rtol=1e-3), "gathered probabilities are not distributions"
-
-    eng0 = engines[0]
-    pred = None if dry else eng0.pred
-    serial, roof, fam_out = None, None, {}
-    if rank == 0 and not dry:
-        stream = eng0.stream
-        # ---- informational: the same steps strictly serial on one stream (what one predictor alone delivers) ----
-        if P > 1:
-            for _ in range(3):
-                eng0.run()
-            torch.cuda.synchronize(dev)
-            ts = time.perf_counter()
-            for _ in range(args.steps):
-                eng0.run()
-            torch.cuda.synchronize(dev)
-            es = time.perf_counter() - ts
-            serial = {"value": round(rows * args.steps / es, 1), "unit": "img/s", "ms_per_step": round(1e3 * es / args.steps, 4),
-                      "note": "one predictor, one stream, steps back to back (this GPU's shard only): a step LATENCY"}
-
-        # ---- per-launch kernel time, live, HIP events on the launch stream.  One event pair brackets INNER back-to-back
-        # launches of the same instruction: a pair around nothing already reads ~4.7 us on this stack, so a pair per
-        # launch overstated every kernel by ~3 us against rocprofv3's averages; with 4 launches per pair the residue is < 1 us.
-        names = pred.kernel_names()
-        body = [i for i, n_ in enumerate(names) if not n_.startswith("io_copy")]
-        reps, INNER = 5, 4
-        with torch.cuda.stream(stream):
-            ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in body] for _ in range(reps)]
-            for r in range(reps):
-                for j, i in enumerate(body):
-                    ev[r][j][0].record(stream)
-                    for _ in range(INNER):
-                        pred.run_instruction(i)
-                    ev[r][j][1].record(stream)
-        torch.cuda.synchronize(dev)
-        per_inst = {i: float(np.median([ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(reps)])) / INNER
-                    for j, i in enumerate(body)}
-        if cfg["model"] == "conv":
-            o = net["ops"][0]
-            cout, cin, k, _ = o["w"].shape
-            costs = [dict(name="image", family="io_copy", ops=0, bytes=0),
-                     dict(name="y", family="conv3x3", ops=2 * rows * cout * 56 * 56 * cin * k * k,
-                          bytes=rows * (cin * 56 * 56 + cout * 56 * 56) + o["w"].size)]
-        else:
-            costs = wl.program_costs(net, rows, eng0.plan)
-        assert len(costs) == len(names), (len(costs), len(names))
-        for i in body:
-            f = fam_out.setdefault(costs[i]["family"], {"launches": 0, "ms": 0.0, "alg_bytes": 0, "ops": 0})
-            f["launches"] += 1
-            f["ms"] += per_inst[i]
-            f["alg_bytes"] += costs[i]["bytes"]
-            f["ops"] += costs[i]["ops"]
-        for f in fam_out.values():
-            f["GB/s"] = round(f["alg_bytes"] / f["ms"] / 1e6, 1)
-            f["TOP/s"] = round(f["ops"] / f["ms"] / 1e9, 2)
-            f["ms"] = round(f["ms"], 4)
-        if args.layer_table:
+                costs = wl.program_costs(net, rows, eng0.plan)
+            assert len(costs) == len(names), (len(costs), len(names))
             for i in body:
-                print("%-28s %-16s %8.4f ms  %7.1f GB/s %7.1f TOP/s  %s" % (
-                    costs[i]["name"], costs[i]["family"], per_inst[i], costs[i]["bytes"] / per_inst[i] / 1e6,
-                    costs[i]["ops"] / per_inst[i] / 1e9, names[i]), file=sys.stderr)
-        # the dominant family (pointwise keeps the label unless another one is clearly, > 10 %, larger: otherwise
-        # `roofline.kernel` would flip from run to run on MobileNetV1, where pointwise and depthwise are within a few %)
-        dom = max(fam_out, key=lambda k_: fam_out[k_]["ms"])
-        if "pointwise1x1" in fam_out and dom != "pointwise1x1" and fam_out[dom]["ms"] < 1.10 * fam_out["pointwise1x1"]["ms"]:
-            dom = "pointwise1x1"
-        d = fam_out[dom]
-        ai = d["ops"] / max(1, d["alg_bytes"])
-        mfma_bound = ai > BALANCE_OPS_PER_BYTE
-        # HBM-side traffic per launch: from the PMC passes committed under profiles/ (tools/pmc_traffic.py over
-        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script: FETCH_SIZE x2 per the gfx950 correction
-        # + WRITE_SIZE); a file, not a live counter -> named in traffic_source, null when absent for this config
-        traffic, tsrc = None, None
-        tpath = os.path.join(ROOT, "profiles", {"c3": "pmc_traffic.json", "c4": "pmc_traffic_c4.json"}.get(args.config, "none"))
-        if os.path.exists(tpath) and rows == cfg["batch"]:
-            try:
-                tj = json.load(open(tpath))
-                t_ = tj.get(dom)
-                if t_:
-                    traffic = round(t_["fetch_bytes_per_launch_x2"] + t_["write_bytes_per_launch"])
-                    tsrc = "profiles/pmc_traffic.json @ %s (not measured in this run)" % tj.get("commit", "round 1")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        roof = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",
-                "achieved": d["TOP/s"] if mfma_bound else d["GB/s"], "peak": round(MFMA_I8_PEAK_TOPS, 1) if mfma_bound else HBM_PEAK_GBS,
-                "unit": "TOP/s" if mfma_bound else "GB/s",
-                "frac": round((d["TOP/s"] / MFMA_I8_PEAK_TOPS) if mfma_bound else (d["GB/s"] / HBM_PEAK_GBS), 4),
-                "traffic": traffic, "traffic_source": tsrc,
-                "avg_launch_ms": round(d["ms"] / d["launches"], 5), "launches_per_step": d["launches"],
-                "alg_bytes_per_launch": round(d["alg_bytes"] / d["launches"]), "alg_ops_per_byte": round(ai, 1),
-                "hbm_GB/s": d["GB/s"], "hbm_frac": round(d["GB/s"] / HBM_PEAK_GBS, 4),
-                "mfma_TOP/s": d["TOP/s"], "mfma_frac_of_dense_i8_peak": round(d["TOP/s"] / MFMA_I8_PEAK_TOPS, 4),
-                "note": "family aggregate: algorithmic bytes = unique input + weights + output once per launch (SURVEY.md 8d), "
-                        "summed over the family's launches of one step, / summed launch time (HIP events on the launch "
-                        "stream, 4 launches per event pair); bound = mfma iff ops/byte > %.0f" % BALANCE_OPS_PER_BYTE}
+                f = fam_out.setdefault(costs[i]["family"], {"launches": 0, "ms": 0.0, "alg_bytes": 0, "ops": 0})
+                f["launches"] += 1
+                f["ms"] += per_inst[i]
+                f["alg_bytes"] += costs[i]["bytes"]
+                f["ops"] += costs[i]["ops"]
+            for f in fam_out.values():
+                f["GB/s"] = round(f["alg_bytes"] / f["ms"] / 1e6, 1)
+                f["TOP/s"] = round(f["ops"] / f["ms"] / 1e9, 2)
+                f["ms"] = round(f["ms"], 4)
+            if args.layer_table:
+                for i in body:
+                    print("%-28s %-16s %8.4f ms  %7.1f GB/s %7.1f TOP/s  %s" % (
+                        costs[i]["name"], costs[i]["family"], per_inst[i], costs[i]["bytes"] / per_inst[i] / 1e6,
+                        costs[i]["ops"] / per_inst[i] / 1e9, names[i]), file=sys.stderr)
+            # the dominant family (pointwise keeps the label unless another one is clearly, > 10 %, larger: otherwise
+            # `roofline.kernel` would flip from run to run on MobileNetV1, where pointwise and depthwise are within a few %)
+            dom = max(fam_out, key=lambda k_: fam_out[k_]["ms"])
+            if "pointwise1x1" in fam_out and dom != "pointwise1x1" and fam_out[dom]["ms"] < 1.10 * fam_out["pointwise1x1"]["ms"]:
+                dom = "pointwise1x1"
+            d = fam_out[dom]
+            ai = d["ops"] / max(1, d["alg_bytes"])
+            mfma_bound = ai > BALANCE_OPS_PER_BYTE
+            # HBM-side traffic per launch: from the PMC passes committed under profiles/ (tools/pmc_traffic.py over
+            # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script: FETCH_SIZE x2 per the gfx950 correction
+            # + WRITE_SIZE); a file, not a live counter -> named in traffic_source, null when absent for this config
+            traffic, tsrc = None, None
+            tpath = os.path.join(ROOT, "profiles", {"c3": "pmc_traffic.json", "c4": "pmc_traffic_c4.json"}.get(args.config, "none"))
+            if os.path.exists(tpath) and rows == cfg["batch"]:
+                try:
+                    tj = json.load(open(tpath))
+                    t_ = tj.get(dom)
+                    if t_:
+                        traffic = round(t_["fetch_bytes_per_launch_x2"] + t_["write_bytes_per_launch"])
+                        tsrc = "profiles/pmc_traffic.json @ %s (not measured in this run)" % tj.get("commit", "round 1")
+                except Exception:  # noqa: BLE001
+                    traffic = None
+            roof = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",
+                    "achieved": d["TOP/s"] if mfma_bound else d["GB/s"], "peak": round(MFMA_I8_PEAK_TOPS, 1) if mfma_bound else HBM_PEAK_GBS,
+                    "unit": "TOP/s" if mfma_bound else "GB/s",
+                    "frac": round((d["TOP/s"] / MFMA_I8_PEAK_TOPS) if mfma_bound else (d["GB/s"] / HBM_PEAK_GBS), 4),
+                    "traffic": traffic, "traffic_source": tsrc,
+                    "avg_launch_ms": round(d["ms"] / d["launches"], 5), "launches_per_step": d["launches"],
+                    "alg_bytes_per_launch": round(d["alg_bytes"] / d["launches"]), "alg_ops_per_byte": round(ai, 1),
+                    "hbm_GB/s": d["GB/s"], "hbm_frac": round(d["GB/s"] / HBM_PEAK_GBS, 4),
+                    "mfma_TOP/s": d["TOP/s"], "mfma_frac_of_dense_i8_peak": round(d["TOP/s"] / MFMA_I8_PEAK_TOPS, 4),
+                    "note": "family aggregate: algorithmic bytes = unique input + weights + output once per launch (SURVEY.md 8d), "
+                            "summed over the family's launches of one step, / summed launch time (HIP events on the launch "
+                            "stream, 4 launches per event pair); bound = mfma iff ops/byte > %.0f" % BALANCE_OPS_PER_BYTE}
 
-    # ---- self-check, outside the timed region: what the timed program computed for the first two images of this rank's
-    # shard must equal the oracle's result for the same bytes (int8 tensors bit for bit, fp32 within the tolerance of the
-    # parity tests); a mismatch makes the run fail instead of printing a rate for garbage
-    selfcheck = None
-    if rank == 0 and not dry and check_images is not None and not args.no_selfcheck:
-        selfcheck = oracle_selfcheck(np, pred, net, cfg, check_images, eng0.out_var)
-        if not selfcheck["ok"]:
-            sys.stderr.write("bench.py: SELF-CHECK FAILED: %s\n" % json.dumps(selfcheck))
-            real_stdout.flush()
-            os._exit(3)
+        # ---- self-check, outside the timed region: what the timed program computed for the first two images of this rank's
+        # shard must equal the oracle's result for the same bytes (int8 tensors bit for bit, fp32 within the tolerance of the
+        # parity tests); a mismatch makes the run fail instead of printing a rate for garbage
+        selfcheck = None
+        if details and rank == 0 and not dry and check_images is not None and not args.no_selfcheck:
+            selfcheck = oracle_selfcheck(np, pred, net, cfg, check_images, eng0.out_var)
+            if not selfcheck["ok"]:
+                sys.stderr.write("bench.py: SELF-CHECK FAILED: %s\n" % json.dumps(selfcheck))
+                real_stdout.flush()
+                os._exit(3)
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
-        cpu = cpu_baseline(cfg, net, args.cpu_seconds)
+        cpu = None
+        if details and rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
+            cpu = cpu_baseline(cfg, net, args.cpu_seconds)
 
+        for f_ in flights:
+            f_.alive = False
+            f_.cmd.release()
+        for e in engines:
+            if e is not None:
+                e.close()
+        return dict(scaling=scaling, global_batch=global_batch, rows=rows, P=P, elapsed=elapsed, wins=wins, serial=serial,
+                    roof=roof, fam_out=fam_out, selfcheck=selfcheck, cpu=cpu, net=net)
+
+    head_scaling = args.scaling or cfg.get("scaling", "weak")
+    case = run_case(head_scaling, args.global_batch, args.batch, True)
+    # a multi-GPU run of the default (weak: fixed images per GPU) config also times the STRONG point the north star names: one
+    # large batch (1024 images) split over the GPUs; it goes into the line as `strong`, the headline stays as configured
+    strong = None
+    if world > 1 and head_scaling == "weak" and args.scaling is None and cfg["model"] != "conv":
+        sc_ = run_case("strong", args.global_batch or 1024, None, False)
+        strong = {"global_batch": sc_["global_batch"], "images_per_gpu": sc_["rows"], "value": round(sc_["global_batch"] * args.steps / sc_["elapsed"], 1),
+                  "unit": "img/s", "ms_per_step": round(1e3 * sc_["elapsed"] / args.steps, 4), "scaling": "strong",
+                  "note": "same run, same ranks: global batch fixed and split by shard_range; compare with the 1-GPU line of `--scaling strong --global-batch %d`" % sc_["global_batch"]}
+    scaling, global_batch, rows, P, elapsed, wins = (case[k] for k in ("scaling", "global_batch", "rows", "P", "elapsed", "wins"))
+    serial, roof, fam_out, selfcheck, cpu, net = (case[k] for k in ("serial", "roof", "fam_out", "selfcheck", "cpu", "net"))
     if rank == 0:
         total_imgs = global_batch * args.steps
         val = total_imgs / elapsed
@@ -669,17 +693,11 @@ def main():
             "windows": {"count": len(wins), "steps_each": args.steps,
                         "ms_per_step_min_median_max": [round(1e3 * min(wins) / args.steps, 4), round(1e3 * elapsed / args.steps, 4),
                                                        round(1e3 * max(wins) / args.steps, 4)]},
-            "selfcheck": selfcheck,
+            "selfcheck": selfcheck, "strong": strong,
             "single_stream": serial, "roofline": roof, "kernels": fam_out, "cpu_baseline": cpu,
         }
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
-    for f_ in flights:
-        f_.alive = False
-        f_.cmd.release()
-    for e in engines:
-        if e is not None:
-            e.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

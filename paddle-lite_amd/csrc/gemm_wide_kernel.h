@@ -309,8 +309,10 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
         const int hw0 = pj < full16 ? pj : g.HWX - 16;
         const int m = mt * 32 + row;
         const v4i o = *reinterpret_cast<const v4i*>(stg + row * SP + cj * 16);
-        if (b < (uint32_t)g.NB && m < g.M)
-          __builtin_memcpy(reinterpret_cast<int8_t*>(g.y) + (size_t)b * g.y_bstride + (size_t)m * (uint32_t)g.HWY + hw0, &o, 16);  // possibly unaligned: fine
+        if (b < (uint32_t)g.NB && m < g.M) {
+          int8_t* yp = reinterpret_cast<int8_t*>(g.y) + (size_t)b * g.y_bstride + (size_t)m * (uint32_t)g.HWY + hw0;  // possibly unaligned: fine
+          __builtin_memcpy(yp, &o, 16);  // (write-through `sc1` stores measured slower: 13.07 vs 12.43 us on the 512 -> 512 layer)
+        }
       }
     } else {
       // 32-bit outputs: register group gq = r >> 2 is 4 consecutive columns: chunk 2t + (gq >> 1), column 8 (gq & 1) + 4h.

@@ -26,6 +26,9 @@ def test_gpus_2_spawns_two_ranks_weak():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 10
     assert line["steps"] == 7 and line["data"] == "dryrun-no-compute" and line["value"] > 0
     assert line["metric"] == "INT8 images/sec MobileNetV1 224x224"
+    # the default (weak) multi-GPU run also carries the strong-scaling point: one large batch split over the ranks
+    st = line["strong"]
+    assert st and st["scaling"] == "strong" and st["global_batch"] == 1024 and st["images_per_gpu"] == 512 and st["value"] > 0
 
 
 def test_strong_scaling_ragged_global_batch_three_ranks():
@@ -34,7 +37,7 @@ def test_strong_scaling_ragged_global_batch_three_ranks():
                          "--global-batch", "7", "--config", "c5", "--res", "32"])
     assert rc == 0, err[-3000:]
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["config"]["global_batch"] == 7
+    assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["config"]["global_batch"] == 7 and line["strong"] is None
     assert "MobileNetV2" in line["metric"]
 
 
