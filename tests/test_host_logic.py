@@ -138,6 +138,11 @@ def test_fused_dwpw_support_query_is_host_only(pkg):
         d = capi.conv_desc(n, c, hw, hw, c, k, k, (k // 2,) * 4, (s, s), (dil, dil), c if groups is None else groups, capi.ACT_RELU, 0.0)
         return lib.plhip_dwpw_fused_supported(ctypes.byref(d), m, out)
 
+    if q(128, 512, 14, 1, 512) == 0:
+        # the default library carries no fused kernel (make EXPERIMENTS=1 builds it): the query must then refuse everything
+        for (c, hw, m) in [(32, 112, 64), (128, 56, 128), (256, 28, 256), (1024, 7, 1024)]:
+            assert q(128, c, hw, 1, m) == 0 and q(4, c, hw, 1, m, out=capi.OUT_F32) == 0, (c, hw, m)
+        return
     for (c, hw, m) in [(32, 112, 64), (128, 56, 128), (256, 28, 256), (512, 14, 512), (1024, 7, 1024)]:
         assert q(128, c, hw, 1, m) == 1, (c, hw, m)
     assert q(128, 64, 112, 2, 128) == 0 and q(128, 512, 14, 2, 1024) == 0
