@@ -1,0 +1,153 @@
+// conv_patch_i8.hip — dense 3x3 stride-1 int8 convolution as an implicit GEMM on input PATCHES: BASELINE config #2 and
+// ResNet50's 3x3 layers.
+//
+// Replaces the reference's im2col + GEMM route for these layers (lite/kernels/arm/conv_gemmlike.cc:125 ->
+// lite/backends/arm/math/conv_impl.cc:490-598 conv_im2col_gemm_int8: im2col_int8 :103-153 + gemm_prepack_int8,
+// gemm_prepacked_int8.cc:2582-2744) and its 3x3 specialisation (conv3x3s1_direct_int8.cc); numerics = the direct int32
+// accumulator + the fused epilogue of conv_block_utils.h:3185-3225.
+//
+// Why a new kernel (round-3 evidence, profiles/r03_final_c2bench.txt, r03_final_layer_table_c4.txt): the ring kernel of
+// gemm_tr_i8.hip runs these layers at 0.08-0.15 of the int8 MFMA peak.  Its K rows are the (channel, tap) pairs, every one
+// fetched from L2 as its own 16-byte pieces: 9x the input per tile through the CU's address path (~21-36 B/clk in that
+// pattern) for 4.6 k cycles of MFMA per 256 x 128 tile, plus the weight panel again for every tile.
+// Here the K loop is re-ordered as (32-channel chunk, column shift s, tap row r):
+//   * on a zero-padded copy whose row pitch PWp is a multiple of 8, output pixel p = oh * PWp + ow (the ow >= OW columns are
+//     computed and dropped) finds tap (r, s) of channel c at padded[c][p + r * PWp + s]: a SHIFT of the flattened plane.
+//     A tile of NT pixels therefore needs, per channel, ONE contiguous run of NT + 2 PWp bytes for all three tap rows, and
+//     one copy of it per column shift s (each starts s bytes later, so that every 8-byte group the transposing LDS read
+//     fetches is aligned): 3 copies instead of 9 K rows, each ~1.5x the tile's pixels: ~4.5 bytes of L2 -> LDS traffic per
+//     pixel and channel instead of 9, in runs of 350-600 contiguous bytes (the fast LDS-DMA pattern, tools/ingest_bench.hip);
+//   * a SLAB = (32 channels) x (that run) of one shift s; per slab a wave issues 3 tap rows x 7 n tiles = 21 MFMAs
+//     (v_mfma_i32_32x32x32_i8, activations = A operand through ds_read_b64_tr_b8, no VALU in the loop): the tap row is an
+//     LDS address offset r * PWp, the n tile an immediate;
+//   * slabs move through a ring of 3-4 slots by LDS-DMA, one barrier per slab (672 cycles of MFMA per wave);
+//   * the channel-row pitch of a slab is an ODD multiple of 32 bytes: the 8 rows x 2 chunks a half-wave's transposed read
+//     touches fall into 16 distinct 16-byte bank slots;
+//   * C = 64 (config #2, ResNet50's res2): the whole weight panel of a wave (32 rows x 576 = 72 VGPRs) stays in
+//     registers for all the tiles the block works through; deeper layers: the slab pair carries the 3 weight fragments
+//     per m tile of its (chunk, s) through the ring (both halves of the block use the same ones);
+//   * the two halves of a block (waves 0-3 / 4-7, SIMD partners) each own a stream of pixel tiles;
+//   * int8 epilogue: requantise (doubled-value trick, gemm_epilogue.h), two v_permlane32_swap -> 16 consecutive pixels
+//     per lane, written into a wave-private LDS image at their COMPACTED position (the dropped columns disappear there),
+//     read back as 16-byte pieces of whole channel rows: a store instruction writes 8 rows x up to 128 contiguous bytes.
+// Weights: [m tile][chunk][s][r][64 lanes][16 B] (launch_pack_conv_patch), lane (m % 32, h) holds channels 16h .. 16h+15.
+#include "conv_patch_kernel.h"
+
+namespace plhip {
+
+__device__ unsigned long long g_patch_stamps[512 * 8 * PATCH_STAMP_SLOTS];
+static unsigned long long* patch_stamps_ptr() {
+  static unsigned long long* p = nullptr;
+  if (!p) (void)hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_patch_stamps));
+  return p;
+}
+int debug_read_patch_stamps(void* dst, size_t bytes) {
+  const size_t cap = sizeof(unsigned long long) * 512 * 8 * PATCH_STAMP_SLOTS;
+  if (bytes > cap) bytes = cap;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_patch_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+
+static int patch_env() {  // PLHIP_CONV_PATCH=0: the ring-kernel implicit GEMM instead (A/B runs)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PLHIP_CONV_PATCH");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+// Row pitch of the padded copy: a multiple of 8 >= w + pl + pr.  The right padding may also be the NEXT row's left padding
+// (pr <= pl: column w + pl + j of a row is column j of the next one, zero for j < pl) — a 7-wide plane with pad 1 fits 8.
+int conv_patch_row_pitch(int w, int pl, int pr) {
+  const int need = pr <= pl ? w + pl : w + pl + pr;
+  return (need + 7) & ~7;
+}
+
+bool conv_patch_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int w, int pl, int pr) {
+  if (!patch_env()) return false;
+  if (kh != 3 || kw != 3 || sh != 1 || sw != 1 || dh != 1 || dw != 1 || groups != 1) return false;
+  if (cin % 32 != 0 || cin < 64 || cout < 32) return false;
+  const int pwp = conv_patch_row_pitch(w, pl, pr);
+  if (pwp > 64 || pwp < 16) return false;   // (7-wide planes: PWp = 8 would need multi-image tiles; the ring kernel keeps them)
+  if (cout <= 64 && cin != 64) return false;  // the 2 x 2 wave layout exists for the register-resident weights only
+  return true;
+}
+
+size_t conv_patch_packed_bytes(int cin, int cout) { return (size_t)((cout + 31) / 32) * (cin / 32) * 9 * 1024; }
+
+__global__ void pack_conv_patch_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp, int cin, int cout, size_t total) {
+  const int NCH = cin / 32;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = idx & 15;
+    const int lane = (idx >> 4) & 63;
+    size_t t = idx >> 10;
+    const int r = t % 3;
+    t /= 3;
+    const int s = t % 3;
+    t /= 3;
+    const int ch = t % NCH;
+    const int mt = (int)(t / NCH);
+    const int m = mt * 32 + (lane & 31);
+    const int c = ch * 32 + 16 * (lane >> 5) + j;
+    wp[idx] = m < cout ? w[(((size_t)m * cin + c) * 3 + r) * 3 + s] : (int8_t)0;
+  }
+}
+
+void launch_pack_conv_patch(const int8_t* w_oihw, int8_t* wp, int cin, int cout, hipStream_t s) {
+  const size_t total = conv_patch_packed_bytes(cin, cout);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_patch_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, wp, cin, cout, total);
+}
+
+static inline void magic_u31(long d, unsigned& m, int& sh) {  // fastdiv_u31's (magic, shift) for divisor d (dw_common.h)
+  int l = 0;
+  while ((1L << l) < d) ++l;
+  if ((1L << l) == d) {
+    m = 0;
+    sh = l;
+    return;
+  }
+  m = (unsigned)(((1ULL << (31 + l)) / (unsigned long long)d) + 1ULL);
+  sh = l - 1;
+}
+
+void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
+  static int dbg_env = -1;
+  if (dbg_env < 0) {
+    const char* e = getenv("PLHIP_GEMM_DEBUG");
+    dbg_env = e ? atoi(e) : 0;
+  }
+  a.dbg = dbg_env;
+  a.stamps = (a.dbg & 32) ? patch_stamps_ptr() : nullptr;
+  a.NCH = a.C / 32;
+  a.HWY = a.OH * a.OW;
+  a.y_bstride = (size_t)a.M * a.HWY;
+  const bool stat = a.NCH == 2;
+  const bool layout_b = a.M <= 64;                // 2 m tiles x 2 pixel groups per half (else 4 x 1)
+  const int NTH = (layout_b ? 2 : 1) * PATCH_NTW * 32;
+  const int WMH = layout_b ? 2 : 4;
+  const long P = (long)a.OH * a.PWp;
+  a.TPI = (int)((P + NTH - 1) / NTH);
+  a.T = a.B * a.TPI;
+  int pitch = (NTH + 2 * a.PWp + 31) & ~31;
+  if (((pitch >> 5) & 1) == 0) pitch += 32;
+  a.pitch = pitch;
+  a.pps = pitch >> 5;
+  a.MB = (a.M + 32 * WMH - 1) / (32 * WMH);
+  const int nq_max = 32 / a.MB > 0 ? 32 / a.MB : 1;
+  int nq = (a.T + 15) / 16;
+  nq = nq < 1 ? 1 : (nq > nq_max ? nq_max : nq);
+  a.rounds = (a.T + 16 * nq - 1) / (16 * nq);
+  nq = (a.T + 16 * a.rounds - 1) / (16 * a.rounds);  // the fewest blocks that need no more rounds
+  a.NQ = nq;
+  magic_u31(a.PWp, a.pw_m, a.pw_s);
+  magic_u31(a.TPI, a.tpi_m, a.tpi_s);
+  magic_u31(a.pitch, a.pitch_m, a.pitch_s);
+  if (layout_b) launch_patch_stat_b(a, out, s);
+  else if (stat) launch_patch_stat_a(a, out, s);
+  else launch_patch_stream_a(a, out, s);
+}
+
+void launch_patch_stat_a(const PatchArgs& a, int out, hipStream_t s) { launch_patch_o<4, 1, 3, 4, true>(a, out, s); }
+
+}  // namespace plhip

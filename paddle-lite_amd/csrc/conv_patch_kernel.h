@@ -1,0 +1,480 @@
+// conv_patch_kernel.h — the dense 3x3 stride-1 convolution as an implicit GEMM on input PATCHES (kernel template +
+// launchers; included by conv_patch_i8.hip and conv_patch_stream.hip, described in conv_patch_i8.hip).
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "plhip_device.h"
+#include "plhip_kernels.h"
+#include "gemm_tr_common.h"
+#include "dw_common.h"
+
+namespace plhip {
+
+constexpr int PATCH_NTW = 7;           // 32-pixel n tiles per wave and tile
+constexpr int PATCH_SP = 144;          // staging row pitch of the int8 epilogue: 128 bytes + 16
+constexpr int PATCH_STAMP_SLOTS = 32;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void patch_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    patch_static_for<I + 1, N>(std::forward<F>(f));
+  }
+}
+
+#define PLHIP_PATCH_STAMP(i)                                               \
+  do {                                                                     \
+    if (diag && lane == 0) lstamp[i] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+
+// WMH x WNH waves per HALF (waves 0-3 / 4-7 = the SIMD partners): a half owns its own stream of pixel tiles; NPW DMA
+// pieces per wave and slab pair; NSLOT ring slots; STAT: the whole K of the weights stays in registers (C = 64), else the
+// slab pair carries the weight fragments of its (chunk, column shift) through the ring.
+template <int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT, bool NONNEG>
+__global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
+  constexpr int NTW = PATCH_NTW, NTH = WNH * NTW * 32, D = NSLOT - 1;
+  constexpr int WPIECES = STAT ? 0 : 3 * WMH;  // 1-KiB weight pieces of a slab pair
+  static_assert(WMH * WNH == 4 && NSLOT >= 3 && NSLOT <= 4, "layout");
+  PLHIP_PRELOAD(a.xp); PLHIP_PRELOAD(a.wp); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias);
+  PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.M); PLHIP_PRELOAD(a.OH); PLHIP_PRELOAD(a.OW); PLHIP_PRELOAD(a.PWp); PLHIP_PRELOAD(a.PLANE);
+  PLHIP_PRELOAD(a.NCH); PLHIP_PRELOAD(a.pitch); PLHIP_PRELOAD(a.pps); PLHIP_PRELOAD(a.TPI); PLHIP_PRELOAD(a.T);
+  PLHIP_PRELOAD(a.MB); PLHIP_PRELOAD(a.NQ); PLHIP_PRELOAD(a.rounds); PLHIP_PRELOAD(a.HWY); PLHIP_PRELOAD(a.y_bstride);
+  PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha); PLHIP_PRELOAD(a.pw_m); PLHIP_PRELOAD(a.pw_s); PLHIP_PRELOAD(a.tpi_m);
+  PLHIP_PRELOAD(a.tpi_s); PLHIP_PRELOAD(a.pitch_m); PLHIP_PRELOAD(a.pitch_s); PLHIP_PRELOAD(a.dbg); PLHIP_PRELOAD(a.res);
+  PLHIP_PRELOAD(a.y2); PLHIP_PRELOAD(a.inv_scale2); PLHIP_PRELOAD(a.res_relu); PLHIP_PRELOAD(a.stamps);
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring[];        // NSLOT x [half 0: 32 x pitch][half 1][weights]
+  __shared__ __attribute__((aligned(16))) uint8_t stg_all[8 * 32 * PATCH_SP];  // int8 epilogue staging, one image per wave
+  __shared__ unsigned long long stamp_all[8 * PATCH_STAMP_SLOTS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = wave >> 2, wq = wave & 3;
+  const int wm = wq % WMH, wn = wq / WMH;  // wave-uniform
+  const int c = lane & 31, h = lane >> 5;
+  const bool diag = (a.dbg & 32) != 0;
+  unsigned long long* lstamp = stamp_all + wave * PATCH_STAMP_SLOTS;
+  if (diag && lane == 0) {
+    lstamp[0] = __builtin_amdgcn_s_memrealtime();
+    lstamp[1] = __builtin_amdgcn_s_memtime();
+    lstamp[2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  }
+
+  // ---- block -> (XCD, M block, n-block slot); stream of a half = 2 nq + half inside the XCD's contiguous tile range
+  const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
+  const int mb = bq % a.MB, nq = bq / a.MB;
+  const int S = 16 * a.NQ;                             // tile streams in all
+  const int sig0 = bx * 2 * a.NQ + nq * 2;             // stream of half 0 (half 1: + 1)
+  const int sig = sig0 + half;
+  const int MT32 = (a.M + 31) >> 5;
+  const int mt = mb * WMH + wm;                        // my 32-row m tile
+  const int mtc = mt < MT32 ? mt : MT32 - 1;           // tiles past M: any packed tile (their rows are never stored)
+  const int mrow = mt * 32 + c;
+  const int SLAB = 32 * a.pitch;
+  const int SLOTB = 2 * SLAB + WPIECES * 1024;
+  const int NCH = a.NCH;
+
+  // ---- this lane's scale / bias: ordinary loads first and alone, waited for here (dummy use)
+  float sc = 1.f, bi = 0.f;
+  if (OUT != OUT_I32 && mrow < a.M) {
+    sc = a.scale[mrow];
+    if (a.bias) bi = a.bias[mrow];
+  }
+  asm volatile("" ::"v"(sc), "v"(bi));
+
+  // ---- my DMA pieces of every slab pair.  Activation pieces first: piece i = wave + 8 j (j < NPA) is 1 KiB i of the two
+  // slabs [half 0: pps KiB][half 1: pps KiB]: lane -> (channel row, 16 bytes of the row); i >= 2 pps: piece i - 2 pps once
+  // more (same bytes to the same place: the per-step issue count stays a constant).  Then the weight pieces (ring mode):
+  // i = wave + 8 (j - NPA) -> m tile i / 3 of the block, tap row i % 3.
+  constexpr int NPA = STAT ? NPW : NPW - (WPIECES + 7) / 8;
+  // (the 2 x 2 layout with its 72 weight registers has no room to keep the 5 per-lane offsets: it recomputes them per issue)
+  constexpr bool PVO_KEPT = !(STAT && WNH == 2);
+  uint32_t pvo[PVO_KEPT ? NPA : 1];   // per-lane source offset from the (tile, chunk, shift) base of the piece's half
+  int pai[NPA];                       // piece index i (wave-uniform)
+  auto piece_offset = [&](int i, uint32_t ln) __attribute__((always_inline)) -> uint32_t {
+    const uint32_t pos = (uint32_t)(i >= a.pps ? i - a.pps : i) * 1024u + ln * 16u;
+    const uint32_t row = fastdiv_u31(pos, a.pitch_m, a.pitch_s);
+    return row * (uint32_t)a.PLANE + (pos - row * (uint32_t)a.pitch);
+  };
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    int i = wave + 8 * j;
+    if (i >= 2 * a.pps) i -= 2 * a.pps;
+    if (i >= 2 * a.pps) i = 0;
+    pai[j] = i;
+    if constexpr (PVO_KEPT) pvo[j] = piece_offset(i, (uint32_t)lane);
+  }
+  uint32_t pwoff[STAT ? 1 : NPW - NPA];  // weight piece: byte offset of its (m tile, r) fragment at (chunk 0, s 0); wave-uniform
+  int pwi[STAT ? 1 : NPW - NPA];
+  if constexpr (!STAT) {
+#pragma unroll
+    for (int j = 0; j < NPW - NPA; ++j) {
+      int iw = wave + 8 * j;
+      if (iw >= WPIECES) iw -= 8;
+      if (iw >= WPIECES) iw = 0;
+      const int mtl = iw / 3, r = iw - mtl * 3;
+      int mtw = mb * WMH + mtl;
+      mtw = mtw < MT32 ? mtw : MT32 - 1;
+      pwi[j] = iw;
+      pwoff[j] = (uint32_t)((mtw * NCH * 9 + r) * 1024);
+    }
+  }
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+
+  // ---- weights in registers (STAT): [chunk][s][r] fragments of my m tile, loaded once
+  v4i w[STAT ? 18 : 1];
+  if constexpr (STAT) {
+    const uint8_t* wbase = reinterpret_cast<const uint8_t*>(a.wp) + (size_t)mtc * (18 * 1024);  // wave-uniform
+    patch_static_for<0, 18>([&](auto i_c) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_c)::value;
+      const uint32_t vo = (uint32_t)lane * 16u + (uint32_t)(i >> 2) * 4096u;
+      if constexpr ((i & 3) == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
+      else if constexpr ((i & 3) == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
+      else if constexpr ((i & 3) == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
+      else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
+    });
+  }
+
+  // ---- DMA issue of the slab pair (cursor tile bases cb[0 / 1], chunk ic, shift is) into ring slot `slot`
+  const uint8_t* cb[2];  // base of the cursor's tile of half 0 / 1 in the padded copy (channel 0, shift 0); wave-uniform
+  auto cursor_tiles = [&](int ik) __attribute__((always_inline)) {
+    ik = ik < a.rounds ? ik : a.rounds - 1;  // past the end: a harmless re-fetch (keeps the per-step issue count constant)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      int t = ik * S + sig0 + hf;
+      t = t < a.T ? t : a.T - 1;
+      const uint32_t b = fastdiv_u31((uint32_t)t, a.tpi_m, a.tpi_s);
+      const int p0 = (t - (int)b * a.TPI) * NTH;
+      cb[hf] = reinterpret_cast<const uint8_t*>(a.xp) + (size_t)b * a.C * (uint32_t)a.PLANE + p0;
+    }
+  };
+  auto issue = [&](int ic, int is, int slot) __attribute__((always_inline)) {
+    const size_t coff = (size_t)(ic * 32) * (uint32_t)a.PLANE + is;
+    uint8_t* sb = ring + slot * SLOTB;
+    uint32_t ln = (uint32_t)lane;
+    if constexpr (!PVO_KEPT) asm volatile("" : "+v"(ln));  // (opaque: not hoisted back out of the loop)
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const uint8_t* sbase = (pai[j] >= a.pps ? cb[1] : cb[0]) + coff;  // wave-uniform
+      uint32_t vo;
+      if constexpr (PVO_KEPT) vo = pvo[j];
+      else vo = piece_offset(pai[j], ln);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(sbase + vo), (lds_ptr_t)(sb + pai[j] * 1024), 16, 0, 0);
+    }
+    if constexpr (!STAT) {
+      const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.wp) + (size_t)(ic * 9 + is * 3) * 1024;
+#pragma unroll
+      for (int j = 0; j < NPW - NPA; ++j)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + pwoff[j] + lane16), (lds_ptr_t)(sb + 2 * SLAB + pwi[j] * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses: lane 2q'+p of a 16-lane group -> channel row q', 8-byte sub-chunk p; group parity -> 16-pixel
+  // chunk; k half h -> channels 16h .. 16h+15 (lo: +0..7, hi: +8..15)
+  const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring;
+  const uint32_t fa = ring_addr + half * SLAB + (16 * h + ((lane & 15) >> 1)) * a.pitch + wn * (NTW * 32) + ((lane >> 4) & 1) * 16 + (lane & 1) * 8;
+  const uint32_t wa = ring_addr + 2 * SLAB + (wm * 3) * 1024 + lane * 16;
+  const uint32_t pitch8 = 8u * (uint32_t)a.pitch;
+
+  v16i acc[NTW];
+  v2i flo[4], fhi[4];  // fragment ring: 3 reads ahead
+  v4i wr[3];           // weight fragments of the step (ring mode)
+
+  // ---- epilogue constants
+  const float hi2 = a.act == ACT_RELU6 ? fminf(a.alpha + a.alpha, 254.f) : 254.f;
+  const float lo2 = NONNEG ? 0.f : -254.f;
+  const float s2 = sc + sc, b2 = bi + bi;
+  const float leak = a.act == ACT_LEAKY ? a.alpha : 1.f;  // int8, !NONNEG: none = leaky with slope 1
+  uint8_t* stg = stg_all + wave * (32 * PATCH_SP);
+
+  // destination offset (inside a channel plane) of p-space pixel p: rows are OW of PWp wide; p past the image -> its end
+  auto dst_of = [&](uint32_t p, int& valid, int span) __attribute__((always_inline)) -> int {
+    const uint32_t oh = fastdiv_u31(p, a.pw_m, a.pw_s);
+    const int ow0 = (int)(p - oh * (uint32_t)a.PWp);
+    int v = a.OW - ow0;
+    v = v < 0 ? 0 : (v > span ? span : v);
+    valid = (int)oh < a.OH ? v : 0;
+    return (int)oh < a.OH ? (int)oh * a.OW + (ow0 < a.OW ? ow0 : a.OW) : a.OH * a.OW;
+  };
+
+  auto epilogue = [&](int b, int p0, int mt) __attribute__((always_inline)) {  // (mt: an opaque copy, see the call)
+    const int pw0 = p0 + wn * (NTW * 32);  // first pixel of my n tiles
+    const int mrow = mt * 32 + c;
+    if constexpr (OUT == OUT_I8) {
+      int8_t* yb = reinterpret_cast<int8_t*>(a.y) + (size_t)b * a.y_bstride;
+      patch_static_for<0, 2>([&](auto g_c) __attribute__((always_inline)) {
+        constexpr int gi = decltype(g_c)::value;
+        constexpr int nt0 = gi * 4, cnt = gi == 0 ? 4 : NTW - 4;
+        int dummy;
+        const int d_a = dst_of((uint32_t)(pw0 + 32 * nt0), dummy, 0);
+        const int d_b = dst_of((uint32_t)(pw0 + 32 * (nt0 + cnt)), dummy, 0);
+        patch_static_for<0, cnt>([&](auto t_c) __attribute__((always_inline)) {
+          constexpr int t = decltype(t_c)::value;
+          const v4i ch = NONNEG ? tr_requant_chunk<ACT_RELU>(acc[nt0 + t], s2, b2, leak, lo2, hi2)
+                                : tr_requant_chunk<ACT_LEAKY>(acc[nt0 + t], s2, b2, leak, lo2, hi2);
+          const uint32_t p = (uint32_t)(pw0 + 32 * (nt0 + t) + 16 * h);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {  // two 8-pixel pieces, each inside one row (PWp % 8 == 0)
+            int valid;
+            const int d = dst_of(p + 8 * e, valid, 8);
+            uint8_t* q = stg + c * PATCH_SP + (d - d_a);
+            const uint32_t v0 = (uint32_t)ch[2 * e], v1 = (uint32_t)ch[2 * e + 1];
+            if (valid == 8 && ((d - d_a) & 3) == 0) {
+              *reinterpret_cast<uint32_t*>(q) = v0;
+              *reinterpret_cast<uint32_t*>(q + 4) = v1;
+            } else if (valid > 0) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                if (k < valid) q[k] = (uint8_t)((k < 4 ? v0 : v1) >> (8 * (k & 3)));
+            }
+          }
+        });
+        const int len = d_b - d_a;  // <= 128
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 8 + (lane >> 3), off = (lane & 7) * 16;
+          const int m = mt * 32 + row;
+          if (off < len && m < a.M) {
+            const v4i v = *reinterpret_cast<const v4i*>(stg + row * PATCH_SP + off);
+            store_chunk_i8(yb + (size_t)m * (uint32_t)a.HWY + d_a + off, (uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3], 0, len - off);
+          }
+        }
+      });
+    } else {
+      // 32-bit outputs: register group gq of n tile t = 4 consecutive pixels 32t + 8gq + 4h (inside one row: PWp % 4 == 0)
+      const float fcap = a.act == ACT_RELU6 ? a.alpha : __builtin_huge_valf();
+      const float flo_ = (a.act == ACT_RELU || a.act == ACT_RELU6) ? 0.f : -__builtin_huge_valf();
+      patch_static_for<0, NTW>([&](auto t_c) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          int valid;
+          const int d = dst_of((uint32_t)(pw0 + 32 * t + 8 * gq + 4 * h), valid, 4);
+          if (valid == 0 || mrow >= a.M) continue;
+          const size_t yoff = (size_t)b * a.y_bstride + (size_t)mrow * (uint32_t)a.HWY + d;
+          if constexpr (OUT == OUT_I32) {
+            int* yp = reinterpret_cast<int*>(a.y) + yoff;
+            if (valid == 4) {
+              const v4i v = {acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]};
+              __builtin_memcpy(yp, &v, 16);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (e < valid) yp[e] = acc[t][4 * gq + e];
+            }
+          } else {
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float yv = __fmaf_rn((float)acc[t][4 * gq + e], sc, bi);
+              if (a.act == ACT_LEAKY) yv = yv > 0.f ? yv : a.alpha * yv;  // kernel-uniform
+              f[e] = fminf(fmaxf(yv, flo_), fcap);
+            }
+            if (a.res) {  // fused residual add (+ relu): kernel-uniform
+              const float* rp = a.res + yoff;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (e < valid) f[e] = f[e] + rp[e];
+                if (a.res_relu) f[e] = f[e] > 0.f ? f[e] : 0.f;
+              }
+            }
+            if (a.y) {
+              float* yp = reinterpret_cast<float*>(a.y) + yoff;
+              if (valid == 4) {
+                const v4f v = {f[0], f[1], f[2], f[3]};
+                __builtin_memcpy(yp, &v, 16);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (e < valid) yp[e] = f[e];
+              }
+            }
+            if (a.y2) {  // fused calib fp32 -> int8 of the value just produced (type_trans.cc:45,183-184)
+              int8_t* qp = a.y2 + yoff;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (e < valid) qp[e] = (int8_t)round_sat_i8(a.inv_scale2 * f[e]);
+            }
+          }
+        }
+      });
+    }
+  };
+
+  // ---- one step = one slab pair: 3 tap rows x NTW n tiles of MFMAs from my half's slab.
+  // CH >= 0: chunk known at compile time (STAT); SS: column shift s; FIRST / LAST: first / last slab of a tile.
+  int slot = 0;                  // ring slot of the current step
+  int nstep = 0;                 // steps done (diagnostic stamps of the first six)
+  int iqk = 0, iqc = 0, iqs = 0; // issue cursor: the slab pair D steps ahead
+  auto advance_cursor = [&]() __attribute__((always_inline)) {
+    if (++iqs == 3) {
+      iqs = 0;
+      if (++iqc == NCH) {
+        iqc = 0;
+        ++iqk;
+        cursor_tiles(iqk);
+      }
+    }
+  };
+  // FIRST: 0 = not the first slab of a tile, 1 = the first (the accumulators start from the constant 0 operand), 2 = run
+  // time (`first`: the accumulators are zeroed)
+  auto step = [&](auto ch_c, auto ss_c, auto first_c, bool first, bool active) __attribute__((always_inline)) {
+    constexpr int CH = decltype(ch_c)::value, SS = decltype(ss_c)::value, FIRST = decltype(first_c)::value;
+    // my pieces of this slab pair have landed (counted: everything issued after them may still fly) ...
+    constexpr int WAITN = (D - 1) * NPW;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_s_barrier();  // ... everyone's have, and nobody reads the previous step's slot any more
+    if (diag && nstep < 6 && lane == 0) lstamp[5 + nstep] = __builtin_amdgcn_s_memtime();
+    {
+      int islot = slot + D;
+      islot = islot >= NSLOT ? islot - NSLOT : islot;
+      issue(iqc, iqs, islot);
+      advance_cursor();
+    }
+    const uint32_t sb = (uint32_t)(slot * SLOTB);
+    if (active) {
+      if (FIRST == 2 && first) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+      }
+      uint32_t alo[3], ahi[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        alo[r] = fa + sb + (uint32_t)(r * a.PWp);
+        ahi[r] = alo[r] + pitch8;
+      }
+      if constexpr (!STAT) {
+        const uint32_t wab = wa + sb;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wr[0]) : "v"(wab) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(wr[1]) : "v"(wab) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wr[2]) : "v"(wab) : "memory");
+      }
+      constexpr int NM = 3 * NTW;  // MFMA i <-> (tap row i / NTW, n tile i % NTW)
+#define PLHIP_PATCH_READ(I_)                                                                                              \
+  do {                                                                                                                    \
+    constexpr int r_ = (I_) / NTW, t_ = (I_) % NTW, f_ = (I_) & 3;                                                        \
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(flo[f_]) : "v"(alo[r_]), "n"(t_ * 32) : "memory");           \
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(fhi[f_]) : "v"(ahi[r_]), "n"(t_ * 32) : "memory");           \
+  } while (0)
+      PLHIP_PATCH_READ(0);
+      PLHIP_PATCH_READ(1);
+      PLHIP_PATCH_READ(2);
+      if constexpr (!STAT) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2])::"memory");
+      patch_static_for<0, NM>([&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        constexpr int r = i / NTW, t = i % NTW, f = i & 3;
+        constexpr int younger = (NM - 1 - i) < 2 ? 2 * (NM - 1 - i) : 4;
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(flo[f]), "+v"(fhi[f]) : "n"(younger) : "memory");
+        const v4i av = {flo[f][0], flo[f][1], fhi[f][0], fhi[f][1]};
+        if constexpr (STAT) {
+          if constexpr (FIRST == 1 && r == 0) {
+            const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, w[(CH * 3 + SS) * 3 + r], zero, 0, 0, 0);
+          } else {
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, w[(CH * 3 + SS) * 3 + r], acc[t], 0, 0, 0);
+          }
+        } else {
+          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wr[r], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i + 3 < NM) PLHIP_PATCH_READ(i + 3);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#undef PLHIP_PATCH_READ
+    }
+    if (diag && nstep < 6 && lane == 0) lstamp[11 + nstep] = __builtin_amdgcn_s_memtime();
+    ++nstep;
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+  };
+
+  // ---- prologue: the slab pairs of the first D steps
+  cursor_tiles(0);
+  for (int p = 0; p < D; ++p) {
+    issue(iqc, iqs, p);
+    advance_cursor();
+  }
+  if constexpr (STAT) {
+    // every weight fragment (issued before the first DMA piece) has landed before an MFMA names it: vmcnt(D * NPW) leaves
+    // only the DMA pieces in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NPW) : "memory");
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]));
+    asm volatile("" : "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]), "+v"(w[16]), "+v"(w[17]));
+  }
+  PLHIP_PATCH_STAMP(3);
+
+  using std::integral_constant;
+  int nstamp = 17;  // 5-10: barrier of step i passed, 11-16: its MFMAs issued, 17..: end of round k (epilogue instructions issued)
+  for (int k = 0; k < a.rounds; ++k) {
+    const int t = k * S + sig;
+    const bool active = t < a.T;                                   // wave-uniform
+    const int tc = active ? t : a.T - 1;
+    const int b = (int)fastdiv_u31((uint32_t)tc, a.tpi_m, a.tpi_s);
+    const int p0 = (tc - b * a.TPI) * NTH;
+    if constexpr (STAT) {
+      typedef integral_constant<int, 0> I0;
+      typedef integral_constant<int, 1> I1;
+      typedef integral_constant<int, 2> I2;
+      step(I0{}, I0{}, I1{}, false, active);
+      step(I0{}, I1{}, I0{}, false, active);
+      step(I0{}, I2{}, I0{}, false, active);
+      step(I1{}, I0{}, I0{}, false, active);
+      step(I1{}, I1{}, I0{}, false, active);
+      step(I1{}, I2{}, I0{}, false, active);
+    } else {
+      for (int ic = 0; ic < NCH; ++ic) {
+        typedef integral_constant<int, -1> IR;
+        step(IR{}, integral_constant<int, 0>{}, integral_constant<int, 2>{}, ic == 0, active);
+        step(IR{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, false, active);
+        step(IR{}, integral_constant<int, 2>{}, integral_constant<int, 0>{}, false, active);
+      }
+    }
+    if (active) {
+      // (opaque copies: the address arithmetic of the epilogue must not be hoisted above the K loop, where its lane masks
+      // and offsets would sit in registers for the whole tile)
+      int be = b, pe = p0, me = mt;
+      asm volatile("" : "+s"(be), "+s"(pe), "+s"(me));
+      epilogue(be, pe, me);
+    }
+    if (nstamp < PATCH_STAMP_SLOTS - 3) {
+      PLHIP_PATCH_STAMP(nstamp);
+      ++nstamp;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMA pieces must land before the LDS is released
+  if (diag) {  // wave-uniform
+    if (lane == 0) {
+      lstamp[PATCH_STAMP_SLOTS - 2] = __builtin_amdgcn_s_memtime();
+      lstamp[PATCH_STAMP_SLOTS - 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (a.stamps && blockIdx.x < 512 && lane < PATCH_STAMP_SLOTS)
+      a.stamps[((size_t)blockIdx.x * 8 + wave) * PATCH_STAMP_SLOTS + lane] = lstamp[lane];
+  }
+}
+
+template <int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT>
+static inline void launch_patch_t(const PatchArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)NSLOT * (2 * 32 * a.pitch + (STAT ? 0 : 3 * WMH * 1024));
+  const unsigned blocks = (unsigned)(8 * a.MB * a.NQ);
+  const bool nonneg = a.act == ACT_RELU || a.act == ACT_RELU6;
+  if (OUT == OUT_I8 && !nonneg) {
+    auto kfn = conv_patch_i8_kernel<WMH, WNH, NPW, NSLOT, STAT, OUT, false>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+  } else {
+    auto kfn = conv_patch_i8_kernel<WMH, WNH, NPW, NSLOT, STAT, OUT, true>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+  }
+}
+
+template <int WMH, int WNH, int NPW, int NSLOT, bool STAT>
+static inline void launch_patch_o(const PatchArgs& a, int out, hipStream_t s) {
+  if (out == OUT_I32) launch_patch_t<WMH, WNH, NPW, NSLOT, STAT, OUT_I32>(a, s);
+  else if (out == OUT_F32) launch_patch_t<WMH, WNH, NPW, NSLOT, STAT, OUT_F32>(a, s);
+  else launch_patch_t<WMH, WNH, NPW, NSLOT, STAT, OUT_I8>(a, s);
+}
+
+}  // namespace plhip

@@ -44,7 +44,7 @@ plhip_status fail(plhip_ctx* c, plhip_status st, const char* fmt, const char* a 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
-enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2, IMPL_IMPLICIT_GEMM = 3 };
+enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2, IMPL_IMPLICIT_GEMM = 3, IMPL_PATCH_GEMM = 4 };
 
 struct ConvGeom {
   int oh, ow, G, Mg, Cg, Kg, N, Np, MA, MT, MT32, KS;
@@ -71,6 +71,13 @@ static void padded_dims(const plhip_conv_desc* d, int* ph, int* pw) {
     *ph = PH;
     *pw = PW;
   }
+}
+// the padded copy of the patch route (conv_patch_i8.hip): rows of PWp (a multiple of 8) bytes, + slack for the tiles that run
+// past the last plane
+static size_t patch_input_bytes(const plhip_conv_desc* d) {
+  const int pwp = plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3]);
+  const size_t b = (size_t)d->n * d->cin * (d->h + d->pad[0] + d->pad[1]) * pwp;
+  return ((b + 3) & ~(size_t)3) + 4096;
 }
 static size_t padded_input_bytes(const plhip_conv_desc* d) {  // + slack: the last 16-byte pieces run past the last row
   int ph, pw;
@@ -116,6 +123,15 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   // 128 with K >= 256) skip the im2col buffer: implicit GEMM on a zero-padded copy of the input (1.08x the input
   // instead of kh*kw x: BASELINE config #2 spent 128 of 149 us writing its 57.8 MB im2col buffer)
   const bool s1 = d->stride[0] == 1 && d->stride[1] == 1, s2 = d->stride[0] == 2 && d->stride[1] == 2;
+  // dense 3x3 stride 1 with Cin % 32 == 0: the patch kernel (conv_patch_i8.hip): 3 shifted copies of the input rows per
+  // 32-channel chunk in LDS instead of 9 K rows per channel
+  if (g->impl == IMPL_IM2COL_GEMM &&
+      plhip::conv_patch_supported(d->cin, d->cout, d->kh, d->kw, d->stride[0], d->stride[1], d->dil[0], d->dil[1], d->groups, d->w,
+                                  d->pad[2], d->pad[3]) &&
+      patch_input_bytes(d) < ((size_t)1 << 31) - 4096 && g->oh >= 1) {
+    g->impl = IMPL_PATCH_GEMM;
+    return true;
+  }
   if (g->impl == IMPL_IM2COL_GEMM && d->groups == 1 && (s1 || s2) && d->dil[0] == 1 && d->dil[1] == 1 && d->kw <= 11 &&
       d->kh * d->kw <= 121 && !implicit_gemm_disabled()) {
     const size_t padded = padded_input_bytes(d);
@@ -280,6 +296,7 @@ size_t plhip_conv_packed_weight_bytes(const plhip_conv_desc* d) {
   ConvGeom g;
   if (!conv_geom(d, &g)) return 0;
   if (g.impl == IMPL_DIRECT_3X3S2) return plhip::conv3x3s2_direct_packed_bytes(d->cin, d->cout);
+  if (g.impl == IMPL_PATCH_GEMM) return plhip::conv_patch_packed_bytes(d->cin, d->cout);
   return (size_t)g.G * g.MT32 * g.KS * 1024;
 }
 
@@ -290,6 +307,8 @@ plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d, c
   if (g.impl == IMPL_DIRECT_3X3S2) {
     if (!aligned(w_packed, 4)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_pack_conv_weights: packed buffer must be 4-byte aligned");
     plhip::launch_pack_conv3x3s2_direct(w_oihw, (uint32_t*)w_packed, d->cin, d->cout, ctx->stream);
+  } else if (g.impl == IMPL_PATCH_GEMM) {
+    plhip::launch_pack_conv_patch(w_oihw, (int8_t*)w_packed, d->cin, d->cout, ctx->stream);
   } else {
     plhip::launch_pack_weights(w_oihw, (int8_t*)w_packed, g.G, g.Mg, g.Kg, g.MT32, g.KS, ctx->stream);
   }
@@ -301,6 +320,7 @@ size_t plhip_conv_workspace_bytes(const plhip_conv_desc* d) {
   ConvGeom g;
   if (!conv_geom(d, &g)) return 0;
   if (g.impl == IMPL_IMPLICIT_GEMM) return padded_input_bytes(d);
+  if (g.impl == IMPL_PATCH_GEMM) return patch_input_bytes(d);
   if (g.impl != IMPL_IM2COL_GEMM) return 0;
   return (size_t)d->n * g.G * g.Kg * g.Np;
 }
@@ -312,6 +332,7 @@ const char* plhip_conv_impl_name(const plhip_conv_desc* d) {
   if (g.impl == IMPL_DIRECT_3X3S2)  // one MFMA K-step when the taps fit (Cin <= 3, OW % 4 == 0), v_dot4 otherwise
     return (d->cin * 3 <= 9 && (g.ow & 3) == 0) ? "conv_3x3s2_direct_int8_mfma32x32x32" : "conv_3x3s2_direct_int8_dot4";
   if (g.impl == IMPL_IMPLICIT_GEMM) return "conv_implicit_gemm_int8_mfma32x32x32";
+  if (g.impl == IMPL_PATCH_GEMM) return "conv_patch_gemm_int8_mfma32x32x32";
   return "conv_im2col_gemm_int8_mfma32x32x32";
 }
 
@@ -355,6 +376,37 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     a.oh = g.oh; a.ow = g.ow; a.pt = d->pad[0]; a.pl = d->pad[2]; a.act = d->act; a.alpha = d->act_alpha;
     plhip::launch_conv3x3s2_direct(a, (int)out, ctx->stream);
     LAUNCHCHK(ctx, "conv3x3s2_direct");
+    return PLHIP_OK;
+  }
+  if (g.impl == IMPL_PATCH_GEMM) {
+    const size_t need = patch_input_bytes(d);
+    if (!workspace || workspace_bytes < need || !aligned(workspace, 4))
+      return fail(ctx, PLHIP_ERR_WORKSPACE, "plhip_conv2d_int8: padded-input workspace missing, too small or unaligned");
+    const int PWp = plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3]), PH = d->h + d->pad[0] + d->pad[1];
+    plhip::PadArgs pa;
+    pa.stride = 1;
+    pa.x = x;
+    pa.xp = (int8_t*)workspace;
+    pa.planes = d->n * d->cin;
+    pa.h = d->h; pa.w = d->w; pa.ph = PH; pa.pw = PWp; pa.pt = d->pad[0]; pa.pl = d->pad[2];
+    pa.total = (long)need;
+    plhip::launch_pad_input(pa, ctx->stream);
+    LAUNCHCHK(ctx, "pad_input");
+    plhip::PatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = (const int8_t*)workspace;
+    a.wp = (const int8_t*)w_packed;
+    a.y = y;
+    a.scale = scale;
+    a.bias = bias;
+    a.B = d->n; a.C = d->cin; a.M = d->cout; a.OH = g.oh; a.OW = g.ow;
+    a.PWp = PWp;
+    a.PLANE = PH * PWp;
+    a.act = d->act;
+    a.alpha = d->act_alpha;
+    a.res = t_res; a.res_relu = t_relu; a.y2 = t_y2; a.inv_scale2 = t_inv;
+    plhip::launch_conv_patch(a, (int)out, ctx->stream);
+    LAUNCHCHK(ctx, "conv_patch");
     return PLHIP_OK;
   }
   if (g.impl == IMPL_IMPLICIT_GEMM) {
@@ -779,6 +831,10 @@ extern "C" int plhip_debug_read_wide_stamps(void* dst_host, size_t bytes) {
   return plhip::debug_read_wide_stamps(dst_host, bytes);
 }
 // tests / A-B runs: force the wide-tile GEMM's n tiles per block (4, 7, 8), 0 = automatic choice, -1 = environment
+extern "C" int plhip_debug_read_patch_stamps(void* dst_host, size_t bytes) {
+  if (!dst_host) return -1;
+  return plhip::debug_read_patch_stamps(dst_host, bytes);
+}
 extern "C" void plhip_debug_wide_ntt(int v) { plhip::debug_set_wide_ntt(v); }
 extern "C" int plhip_debug_read_tr_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();

@@ -58,6 +58,45 @@ struct PadArgs {
 };
 void launch_pad_input(const PadArgs& a, hipStream_t s);
 
+// dense 3x3 stride-1 convolution on input patches (conv_patch_i8.hip)
+struct PatchArgs {
+  const int8_t* xp;    // zero-padded copy [B][C][PH][PWp] (+ slack): padded[ih + pt][iw + pl] = x[ih][iw]
+  const int8_t* wp;    // packed weights [MT32][NCH][3 s][3 r][64 lanes][16 B] (launch_pack_conv_patch)
+  void* y;             // [B][M][OH][OW] int8 / fp32 / int32 (may be nullptr with y2)
+  const float* scale;  // [M] folded per-channel scale (unused for I32)
+  const float* bias;   // [M] or nullptr
+  int B, C, M, OH, OW;
+  int PWp, PLANE;      // row pitch (multiple of 8) and plane size PH * PWp of the padded copy
+  int NCH;             // 32-channel chunks: C / 32
+  int pitch, pps;      // LDS bytes per channel row of a slab (odd multiple of 32, >= tile + 2 PWp), pitch / 32
+  int TPI, T;          // tiles per image, tiles in all
+  int MB, NQ, rounds;  // M blocks, blocks per XCD and M block, tiles per stream
+  int HWY;             // OH * OW
+  size_t y_bstride;    // M * OH * OW
+  int act;
+  float alpha;
+  unsigned pw_m, tpi_m, pitch_m;  // fastdiv_u31 (magic, shift) for PWp, TPI, pitch
+  int pw_s, tpi_s, pitch_s;
+  // fused tail of an fp32-output conv (OUT_F32 only), as GemmArgs
+  const float* res;
+  int res_relu;
+  int8_t* y2;
+  float inv_scale2;
+  int dbg;
+  unsigned long long* stamps;
+};
+// row pitch of the padded copy for (w, pl, pr), 0 = outside the route
+int conv_patch_row_pitch(int w, int pl, int pr);
+bool conv_patch_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int w, int pl, int pr);
+size_t conv_patch_packed_bytes(int cin, int cout);
+void launch_pack_conv_patch(const int8_t* w_oihw, int8_t* wp, int cin, int cout, hipStream_t s);
+// fills the launch plan of `a` (B, C, M, OH, OW, PWp, PLANE set by the caller) and launches
+void launch_conv_patch(PatchArgs a, int out, hipStream_t s);
+void launch_patch_stat_a(const PatchArgs& a, int out, hipStream_t s);    // per-variant translation units
+void launch_patch_stat_b(const PatchArgs& a, int out, hipStream_t s);
+void launch_patch_stream_a(const PatchArgs& a, int out, hipStream_t s);
+int debug_read_patch_stamps(void* dst, size_t bytes);
+
 struct Im2colArgs {
   const int8_t* x;
   int8_t* col;

@@ -313,9 +313,31 @@ def test_implicit_gemm_route(gpu_ctx, pkg, plref):
         (2, 70, 17, 21, 320, 2, 2, (1, 0, 0, 1), 0), (1, 64, 56, 56, 128, 3, 3, (1, 1, 1, 1), 1), (2, 33, 12, 40, 512, 3, 3, (2, 1, 0, 2), 2)]
     for (n, cin, h, w, cout, kh, kw, pads, act) in cases:
         d = capi.conv_desc(n, cin, h, w, cout, kh, kw, pads, (1, 1), (1, 1), 1, act, 0.0)
-        assert gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) == b"conv_implicit_gemm_int8_mfma32x32x32", (cin, cout, kh, kw)
+        name = gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d))
+        patch = kh == 3 and kw == 3 and cin % 32 == 0 and cin >= 64  # 3x3 with whole 32-channel chunks: the patch kernel
+        assert name == (b"conv_patch_gemm_int8_mfma32x32x32" if patch else b"conv_implicit_gemm_int8_mfma32x32x32"), (cin, cout, kh, kw)
         assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, kh, kw, pads, 1, 1, 1, act, 6.0 if act == 2 else 0.25,
                                 act != 4, rng) == 1
+
+
+def test_patch_conv_route(gpu_ctx, pkg, plref):
+    """Dense 3x3 stride-1 convs with Cin % 32 == 0 on the patch kernel (conv_patch_i8.hip): register-resident weights
+    (Cin = 64) in both wave layouts (M > 64: 4 m tiles x 1 pixel group per half, M <= 64: 2 x 2), weights through the ring
+    (Cin > 64), M blocks (M > 128) and M tails, row pitches 16 .. 64 incl. the shared pad column (W + 1 a multiple of 8),
+    asymmetric / zero pads, tiles that end inside an image / past it, several tiles per stream, every activation and
+    output kind."""
+    rng = np.random.default_rng(131)
+    capi = pkg.capi
+    cases = [  # n, cin, h, w, cout, pads(t,b,l,r), act
+        (2, 64, 20, 20, 128, (1, 1, 1, 1), 1), (1, 64, 56, 56, 128, (1, 1, 1, 1), 2), (2, 64, 56, 56, 64, (1, 1, 1, 1), 1),
+        (3, 64, 9, 15, 40, (1, 1, 1, 1), 0), (2, 64, 13, 27, 100, (0, 2, 2, 0), 4), (2, 128, 28, 28, 128, (1, 1, 1, 1), 1),
+        (2, 256, 14, 14, 256, (1, 1, 1, 1), 1), (1, 96, 17, 33, 200, (1, 0, 0, 1), 2), (5, 160, 14, 14, 72, (0, 0, 0, 0), 0),
+        (37, 64, 14, 14, 96, (1, 1, 1, 1), 1), (1, 64, 40, 58, 130, (1, 1, 1, 1), 4)]
+    for (n, cin, h, w, cout, pads, act) in cases:
+        d = capi.conv_desc(n, cin, h, w, cout, 3, 3, pads, (1, 1), (1, 1), 1, act, 0.0)
+        assert gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) == b"conv_patch_gemm_int8_mfma32x32x32", (cin, cout, w, pads)
+        assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 3, 3, pads, 1, 1, 1, act, 6.0 if act == 2 else 0.25,
+                                act != 4, rng) == 1, (n, cin, h, w, cout, pads, act)
 
 
 def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
