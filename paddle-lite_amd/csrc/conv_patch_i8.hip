@@ -99,10 +99,74 @@ void launch_pack_conv_patch(const int8_t* w_oihw, int8_t* wp, int cin, int cout,
   hipLaunchKernelGGL(pack_conv_patch_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, wp, cin, cout, total);
 }
 
-static inline void magic_u31(long d, unsigned& m, int& sh) {  // fastdiv_u31's (magic, shift) for divisor d (dw_common.h)
+// Zero-padded copy for this route: xp[plane][ph][pw] = x[plane][ph - pt][pw - pl] or 0, rows of pw (a multiple of 8) bytes.
+// One thread = 16 aligned output bytes = two 8-byte halves, each inside one padded row: ONE unaligned 8-byte load from a
+// start clamped into the source row, shifted into place (the shift brings the zeros of the left / right border in), one
+// 16-byte store.  (The dword-per-thread copy of the ring route, pad_input_i8_kernel, ran this shape at 0.6 TB/s: 12.8 us
+// for config #2's 7.6 MB — 4-byte loads and stores; profiles/r03_patch_v1_kernel_stats.csv.)
+__global__ __launch_bounds__(256) void pad_rows8_i8_kernel(PadArgs a) {
+  const long nq = a.total >> 4;
+  const uint32_t plane_sz = (uint32_t)a.ph * (uint32_t)a.pw;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    unsigned long long out[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const uint32_t o = ((uint32_t)q << 4) + 8u * e;
+      const uint32_t plane = fastdiv_u31(o, a.div_plane_m, a.div_plane_s);
+      const uint32_t rem = o - plane * plane_sz;
+      const int ph = (int)fastdiv_u31(rem, a.div_pw_m, a.div_pw_s), pc = (int)rem - ph * a.pw;
+      const int ih = ph - a.pt, iw0 = pc - a.pl;
+      unsigned long long v = 0;
+      if ((int)plane < a.planes && ih >= 0 && ih < a.h && iw0 < a.w && iw0 + 8 > 0) {
+        const int8_t* row = a.x + ((size_t)plane * a.h + ih) * a.w;
+        if (a.w >= 8) {
+          const int st = iw0 < 0 ? 0 : (iw0 + 8 > a.w ? a.w - 8 : iw0);
+          __builtin_memcpy(&v, row + st, 8);
+          const int sh = st - iw0;  // > 0: the data starts `sh` columns late (left border); < 0: early (right border)
+          v = sh >= 0 ? v << (8 * sh) : v >> (8 * -sh);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (iw0 + k >= 0 && iw0 + k < a.w) v |= (unsigned long long)(uint8_t)row[iw0 + k] << (8 * k);
+        }
+      }
+      out[e] = v;
+    }
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 o2 = {out[0], out[1]};
+    reinterpret_cast<v2u64*>(a.xp)[q] = o2;
+  }
+}
+
+void launch_pad_rows8(PadArgs a, hipStream_t s) {  // a.pw % 8 == 0, a.total % 16 == 0, a.xp 16-byte aligned
+  unsigned m;
+  int sh;
+  auto magic = [&](long d) {
+    int l = 0;
+    while ((1L << l) < d) ++l;
+    if ((1L << l) == d) {
+      m = 0;
+      sh = l;
+    } else {
+      m = (unsigned)(((1ULL << (31 + l)) / (unsigned long long)d) + 1ULL);
+      sh = l - 1;
+    }
+  };
+  magic((long)a.ph * a.pw);
+  a.div_plane_m = m; a.div_plane_s = sh;
+  magic(a.pw);
+  a.div_pw_m = m; a.div_pw_s = sh;
+  long blocks = ((a.total >> 4) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(pad_rows8_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
+// fastdiv_u31's (magic, shift) for divisor d (dw_common.h); general_pow2: the multiply form for powers of two as well
+// (d >= 2: magic 2^31 + 1, shift l - 1), for device code that must not branch on the marker 0
+static inline void magic_u31(long d, unsigned& m, int& sh, bool general_pow2 = false) {
   int l = 0;
   while ((1L << l) < d) ++l;
-  if ((1L << l) == d) {
+  if ((1L << l) == d && !(general_pow2 && d >= 2)) {
     m = 0;
     sh = l;
     return;
@@ -134,13 +198,23 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   a.pitch = pitch;
   a.pps = pitch >> 5;
   a.MB = (a.M + 32 * WMH - 1) / (32 * WMH);
-  const int nq_max = 32 / a.MB > 0 ? 32 / a.MB : 1;
-  int nq = (a.T + 15) / 16;
+  // blocks: 8 XCDs x MB x NQ, each with NH tile streams; the register-resident variants run 4-wave blocks (NH = 1), two per
+  // CU: 512 blocks fill the chip, the ring variant one 8-wave block (NH = 2) per CU
+  const int NH = stat ? 1 : 2;
+  const int spx = 8 * NH;                                  // streams per unit of NQ
+  const int nq_max = (64 / NH) / a.MB > 0 ? (64 / NH) / a.MB : 1;
+  int nq = (a.T + spx - 1) / spx;
   nq = nq < 1 ? 1 : (nq > nq_max ? nq_max : nq);
-  a.rounds = (a.T + 16 * nq - 1) / (16 * nq);
-  nq = (a.T + 16 * a.rounds - 1) / (16 * a.rounds);  // the fewest blocks that need no more rounds
+  a.rounds = (a.T + spx * nq - 1) / (spx * nq);
+  nq = (a.T + spx * a.rounds - 1) / (spx * a.rounds);  // the fewest blocks that need no more rounds
   a.NQ = nq;
-  magic_u31(a.PWp, a.pw_m, a.pw_s);
+  static int delay_env = -1;
+  if (delay_env < 0) {
+    const char* e = getenv("PLHIP_PATCH_DELAY");  // s_sleep units (64 clocks) the second block of a CU starts late
+    delay_env = e ? atoi(e) : 0;
+  }
+  a.delay = delay_env;
+  magic_u31(a.PWp, a.pw_m, a.pw_s, true);
   magic_u31(a.TPI, a.tpi_m, a.tpi_s);
   magic_u31(a.pitch, a.pitch_m, a.pitch_s);
   if (layout_b) launch_patch_stat_b(a, out, s);
@@ -148,6 +222,6 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   else launch_patch_stream_a(a, out, s);
 }
 
-void launch_patch_stat_a(const PatchArgs& a, int out, hipStream_t s) { launch_patch_o<4, 1, 3, 4, true>(a, out, s); }
+void launch_patch_stat_a(const PatchArgs& a, int out, hipStream_t s) { launch_patch_o<1, 4, 1, 3, 4, true>(a, out, s); }
 
 }  // namespace plhip

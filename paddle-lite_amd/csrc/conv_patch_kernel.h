@@ -30,27 +30,30 @@ __device__ __forceinline__ void patch_static_for(F&& f) {
     if (diag && lane == 0) lstamp[i] = __builtin_amdgcn_s_memtime();       \
   } while (0)
 
-// WMH x WNH waves per HALF (waves 0-3 / 4-7 = the SIMD partners): a half owns its own stream of pixel tiles; NPW DMA
-// pieces per wave and slab pair; NSLOT ring slots; STAT: the whole K of the weights stays in registers (C = 64), else the
-// slab pair carries the weight fragments of its (chunk, column shift) through the ring.
-template <int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT, bool NONNEG>
-__global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
-  constexpr int NTW = PATCH_NTW, NTH = WNH * NTW * 32, D = NSLOT - 1;
-  constexpr int WPIECES = STAT ? 0 : 3 * WMH;  // 1-KiB weight pieces of a slab pair
-  static_assert(WMH * WNH == 4 && NSLOT >= 3 && NSLOT <= 4, "layout");
+// NH halves of 4 waves per block, WMH x WNH waves per half: a half owns its own stream of pixel tiles.  NH = 1: 4-wave
+// blocks, TWO per CU, each with its own ring and its own barriers: the blocks drift apart, so that one's epilogue (VALU,
+// stores) runs beside the other's MFMAs (with one 8-wave block the per-slab barrier keeps the SIMD partners in lock step:
+// both multiply, then both requantise: profiles/r03_patch_timeline_v1_c2.txt).  NH = 2: one 8-wave block per CU whose slab
+// pair shares the weight fragments of its (chunk, shift) through the ring.  NPW DMA pieces per wave and slot; NSLOT ring
+// slots; STAT: the whole K of the weights stays in registers (C = 64), else they travel through the ring.
+template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT, bool NONNEG>
+__global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a) {
+  constexpr int NTW = PATCH_NTW, NTH = WNH * NTW * 32, D = NSLOT - 1, NW = 4 * NH;
+  constexpr int WPIECES = STAT ? 0 : 3 * WMH;  // 1-KiB weight pieces of a slot
+  static_assert(WMH * WNH == 4 && NSLOT >= 3 && NSLOT <= 4 && (NH == 1 || NH == 2), "layout");
   PLHIP_PRELOAD(a.xp); PLHIP_PRELOAD(a.wp); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias);
   PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.M); PLHIP_PRELOAD(a.OH); PLHIP_PRELOAD(a.OW); PLHIP_PRELOAD(a.PWp); PLHIP_PRELOAD(a.PLANE);
   PLHIP_PRELOAD(a.NCH); PLHIP_PRELOAD(a.pitch); PLHIP_PRELOAD(a.pps); PLHIP_PRELOAD(a.TPI); PLHIP_PRELOAD(a.T);
   PLHIP_PRELOAD(a.MB); PLHIP_PRELOAD(a.NQ); PLHIP_PRELOAD(a.rounds); PLHIP_PRELOAD(a.HWY); PLHIP_PRELOAD(a.y_bstride);
   PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha); PLHIP_PRELOAD(a.pw_m); PLHIP_PRELOAD(a.pw_s); PLHIP_PRELOAD(a.tpi_m);
   PLHIP_PRELOAD(a.tpi_s); PLHIP_PRELOAD(a.pitch_m); PLHIP_PRELOAD(a.pitch_s); PLHIP_PRELOAD(a.dbg); PLHIP_PRELOAD(a.res);
-  PLHIP_PRELOAD(a.y2); PLHIP_PRELOAD(a.inv_scale2); PLHIP_PRELOAD(a.res_relu); PLHIP_PRELOAD(a.stamps);
+  PLHIP_PRELOAD(a.y2); PLHIP_PRELOAD(a.inv_scale2); PLHIP_PRELOAD(a.res_relu); PLHIP_PRELOAD(a.stamps); PLHIP_PRELOAD(a.delay);
   extern __shared__ __attribute__((aligned(16))) uint8_t ring[];        // NSLOT x [half 0: 32 x pitch][half 1][weights]
-  __shared__ __attribute__((aligned(16))) uint8_t stg_all[8 * 32 * PATCH_SP];  // int8 epilogue staging, one image per wave
-  __shared__ unsigned long long stamp_all[8 * PATCH_STAMP_SLOTS];
+  __shared__ __attribute__((aligned(16))) uint8_t stg_all[NW * 32 * PATCH_SP];  // int8 epilogue staging, one image per wave
+  __shared__ unsigned long long stamp_all[NW * PATCH_STAMP_SLOTS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = wave >> 2, wq = wave & 3;
+  const int half = NH == 2 ? wave >> 2 : 0, wq = wave & 3;
   const int wm = wq % WMH, wn = wq / WMH;  // wave-uniform
   const int c = lane & 31, h = lane >> 5;
   const bool diag = (a.dbg & 32) != 0;
@@ -64,30 +67,34 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
   // ---- block -> (XCD, M block, n-block slot); stream of a half = 2 nq + half inside the XCD's contiguous tile range
   const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
   const int mb = bq % a.MB, nq = bq / a.MB;
-  const int S = 16 * a.NQ;                             // tile streams in all
-  const int sig0 = bx * 2 * a.NQ + nq * 2;             // stream of half 0 (half 1: + 1)
+  const int S = 8 * NH * a.NQ;                         // tile streams in all
+  const int sig0 = (bx * a.NQ + nq) * NH;              // stream of half 0 (half 1: + 1)
   const int sig = sig0 + half;
   const int MT32 = (a.M + 31) >> 5;
   const int mt = mb * WMH + wm;                        // my 32-row m tile
   const int mtc = mt < MT32 ? mt : MT32 - 1;           // tiles past M: any packed tile (their rows are never stored)
   const int mrow = mt * 32 + c;
   const int SLAB = 32 * a.pitch;
-  const int SLOTB = 2 * SLAB + WPIECES * 1024;
+  const int SLOTB = NH * SLAB + WPIECES * 1024;
   const int NCH = a.NCH;
 
-  // ---- this lane's scale / bias: ordinary loads first and alone, waited for here (dummy use)
+  // ---- this lane's scale / bias: the two oldest loads of the wave, inline asm like every load here (the compiler would
+  // guard an ordinary load with vmcnt(0) at its first use, the epilogue, and drain the DMA pipeline there); every counted
+  // wait below covers them.  Always two loads (no bias: the scale once more) so that the counts are constants.
   float sc = 1.f, bi = 0.f;
-  if (OUT != OUT_I32 && mrow < a.M) {
-    sc = a.scale[mrow];
-    if (a.bias) bi = a.bias[mrow];
+  if constexpr (OUT != OUT_I32) {
+    const uint32_t mo = (uint32_t)(mrow < a.M ? mrow : a.M - 1) * 4u;
+    const float* sp = a.scale;
+    const float* bp = a.bias ? a.bias : a.scale;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(sc) : "v"(mo), "s"(sp) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(bi) : "v"(mo), "s"(bp) : "memory");
   }
-  asm volatile("" ::"v"(sc), "v"(bi));
 
-  // ---- my DMA pieces of every slab pair.  Activation pieces first: piece i = wave + 8 j (j < NPA) is 1 KiB i of the two
-  // slabs [half 0: pps KiB][half 1: pps KiB]: lane -> (channel row, 16 bytes of the row); i >= 2 pps: piece i - 2 pps once
+  // ---- my DMA pieces of every slot.  Activation pieces first: piece i = wave + NW j (j < NPA) is 1 KiB i of the slabs
+  // [half 0: pps KiB][half 1: pps KiB]: lane -> (channel row, 16 bytes of the row); i >= NH pps: piece i - NH pps once
   // more (same bytes to the same place: the per-step issue count stays a constant).  Then the weight pieces (ring mode):
-  // i = wave + 8 (j - NPA) -> m tile i / 3 of the block, tap row i % 3.
-  constexpr int NPA = STAT ? NPW : NPW - (WPIECES + 7) / 8;
+  // i = wave + NW (j - NPA) -> m tile i / 3 of the block, tap row i % 3.
+  constexpr int NPA = STAT ? NPW : NPW - (WPIECES + NW - 1) / NW;
   // (the 2 x 2 layout with its 72 weight registers has no room to keep the 5 per-lane offsets: it recomputes them per issue)
   constexpr bool PVO_KEPT = !(STAT && WNH == 2);
   uint32_t pvo[PVO_KEPT ? NPA : 1];   // per-lane source offset from the (tile, chunk, shift) base of the piece's half
@@ -99,9 +106,9 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
   };
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
-    int i = wave + 8 * j;
-    if (i >= 2 * a.pps) i -= 2 * a.pps;
-    if (i >= 2 * a.pps) i = 0;
+    int i = wave + NW * j;
+    if (i >= NH * a.pps) i -= NH * a.pps;
+    if (i >= NH * a.pps) i = 0;
     pai[j] = i;
     if constexpr (PVO_KEPT) pvo[j] = piece_offset(i, (uint32_t)lane);
   }
@@ -110,8 +117,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
   if constexpr (!STAT) {
 #pragma unroll
     for (int j = 0; j < NPW - NPA; ++j) {
-      int iw = wave + 8 * j;
-      if (iw >= WPIECES) iw -= 8;
+      int iw = wave + NW * j;
+      if (iw >= WPIECES) iw -= NW;
       if (iw >= WPIECES) iw = 0;
       const int mtl = iw / 3, r = iw - mtl * 3;
       int mtw = mb * WMH + mtl;
@@ -122,26 +129,25 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
   }
   const uint32_t lane16 = (uint32_t)lane * 16u;
 
-  // ---- weights in registers (STAT): [chunk][s][r] fragments of my m tile, loaded once
+  // ---- weights in registers (STAT): [chunk][s][r] fragments of my m tile, loaded once (inline asm: invisible to the
+  // compiler's wait-count pass; the counted waits of the first round cover them, see the prologue)
   v4i w[STAT ? 18 : 1];
-  if constexpr (STAT) {
-    const uint8_t* wbase = reinterpret_cast<const uint8_t*>(a.wp) + (size_t)mtc * (18 * 1024);  // wave-uniform
-    patch_static_for<0, 18>([&](auto i_c) __attribute__((always_inline)) {
-      constexpr int i = decltype(i_c)::value;
-      const uint32_t vo = (uint32_t)lane * 16u + (uint32_t)(i >> 2) * 4096u;
-      if constexpr ((i & 3) == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
-      else if constexpr ((i & 3) == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
-      else if constexpr ((i & 3) == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
-      else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
-    });
-  }
+  const uint8_t* wbase = reinterpret_cast<const uint8_t*>(a.wp) + (size_t)mtc * (18 * 1024);  // wave-uniform
+  auto load_w = [&](auto i_c) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value;
+    const uint32_t vo = (uint32_t)lane * 16u + (uint32_t)(i >> 2) * 4096u;
+    if constexpr ((i & 3) == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
+    else if constexpr ((i & 3) == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
+    else if constexpr ((i & 3) == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(w[i]) : "v"(vo), "s"(wbase) : "memory");
+  };
 
   // ---- DMA issue of the slab pair (cursor tile bases cb[0 / 1], chunk ic, shift is) into ring slot `slot`
-  const uint8_t* cb[2];  // base of the cursor's tile of half 0 / 1 in the padded copy (channel 0, shift 0); wave-uniform
+  const uint8_t* cb[NH];  // base of the cursor's tile of half 0 / 1 in the padded copy (channel 0, shift 0); wave-uniform
   auto cursor_tiles = [&](int ik) __attribute__((always_inline)) {
     ik = ik < a.rounds ? ik : a.rounds - 1;  // past the end: a harmless re-fetch (keeps the per-step issue count constant)
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < NH; ++hf) {
       int t = ik * S + sig0 + hf;
       t = t < a.T ? t : a.T - 1;
       const uint32_t b = fastdiv_u31((uint32_t)t, a.tpi_m, a.tpi_s);
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
     if constexpr (!PVO_KEPT) asm volatile("" : "+v"(ln));  // (opaque: not hoisted back out of the loop)
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
-      const uint8_t* sbase = (pai[j] >= a.pps ? cb[1] : cb[0]) + coff;  // wave-uniform
+      const uint8_t* sbase = (NH == 2 && pai[j] >= a.pps ? cb[NH - 1] : cb[0]) + coff;  // wave-uniform
       uint32_t vo;
       if constexpr (PVO_KEPT) vo = pvo[j];
       else vo = piece_offset(pai[j], ln);
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
       const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.wp) + (size_t)(ic * 9 + is * 3) * 1024;
 #pragma unroll
       for (int j = 0; j < NPW - NPA; ++j)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + pwoff[j] + lane16), (lds_ptr_t)(sb + 2 * SLAB + pwi[j] * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + pwoff[j] + lane16), (lds_ptr_t)(sb + NH * SLAB + pwi[j] * 1024), 16, 0, 0);
     }
   };
 
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
   // chunk; k half h -> channels 16h .. 16h+15 (lo: +0..7, hi: +8..15)
   const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring;
   const uint32_t fa = ring_addr + half * SLAB + (16 * h + ((lane & 15) >> 1)) * a.pitch + wn * (NTW * 32) + ((lane >> 4) & 1) * 16 + (lane & 1) * 8;
-  const uint32_t wa = ring_addr + 2 * SLAB + (wm * 3) * 1024 + lane * 16;
+  const uint32_t wa = ring_addr + NH * SLAB + (wm * 3) * 1024 + lane * 16;
   const uint32_t pitch8 = 8u * (uint32_t)a.pitch;
 
   v16i acc[NTW];
@@ -184,25 +190,41 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
   // ---- epilogue constants
   const float hi2 = a.act == ACT_RELU6 ? fminf(a.alpha + a.alpha, 254.f) : 254.f;
   const float lo2 = NONNEG ? 0.f : -254.f;
-  const float s2 = sc + sc, b2 = bi + bi;
   const float leak = a.act == ACT_LEAKY ? a.alpha : 1.f;  // int8, !NONNEG: none = leaky with slope 1
   uint8_t* stg = stg_all + wave * (32 * PATCH_SP);
 
-  // destination offset (inside a channel plane) of p-space pixel p: rows are OW of PWp wide; p past the image -> its end
+  int nepi = 0;  // epilogues done (diagnostic stamps of the first)
+  // destination offset (inside a channel plane) of p-space pixel p: rows are OW of PWp wide; p past the image -> its end.
+  // Branch free (it runs on the scalar unit for wave-uniform p: a branch there is a pipeline bubble per piece): PWp >= 16,
+  // so the host's magic is never the power-of-two marker 0 (launch_conv_patch uses the general form for powers of two too)
   auto dst_of = [&](uint32_t p, int& valid, int span) __attribute__((always_inline)) -> int {
-    const uint32_t oh = fastdiv_u31(p, a.pw_m, a.pw_s);
+    const uint32_t oh = __umulhi(p, a.pw_m) >> a.pw_s;
     const int ow0 = (int)(p - oh * (uint32_t)a.PWp);
+    const int inside = ((int)oh - a.OH) >> 31;  // all ones: the row exists
     int v = a.OW - ow0;
-    v = v < 0 ? 0 : (v > span ? span : v);
-    valid = (int)oh < a.OH ? v : 0;
-    return (int)oh < a.OH ? (int)oh * a.OW + (ow0 < a.OW ? ow0 : a.OW) : a.OH * a.OW;
+    v = v < 0 ? 0 : v;
+    v = v > span ? span : v;
+    const int owc = ow0 < a.OW ? ow0 : a.OW;
+    const int ohc = (int)oh < a.OH ? (int)oh : a.OH;
+    valid = v & inside;
+    return ohc * a.OW + (owc & inside);
   };
 
   auto epilogue = [&](int b, int p0, int mt) __attribute__((always_inline)) {  // (mt: an opaque copy, see the call)
-    const int pw0 = p0 + wn * (NTW * 32);  // first pixel of my n tiles
+    const int pw0 = p0 + wn * (NTW * 32);  // first pixel of my n tiles (wave-uniform: so is every dst_of below -> scalar unit)
     const int mrow = mt * 32 + c;
+    const float bi_ = a.bias ? bi : 0.f;
+    const float s2 = sc + sc, b2 = bi_ + bi_;
     if constexpr (OUT == OUT_I8) {
+      // A lane holds 16 consecutive pixels of its channel per n tile (after the half swap) = two 8-pixel pieces, each inside
+      // one padded row; piece k (k = 2h + e) keeps its first valid_k bytes, which belong at d_k in the dense output row.  The
+      // wave writes the pieces into its staging image IN PIXEL ORDER, all 8 bytes each, at byte d_k - d_a (unaligned
+      // ds_write_b64): the dropped tail of a piece is overwritten by the next one, so the image comes out compacted.  Then
+      // it is read back as 16-byte pieces of whole channel rows: a store instruction writes 8 rows x up to 128 contiguous bytes.
       int8_t* yb = reinterpret_cast<int8_t*>(a.y) + (size_t)b * a.y_bstride;
+      const uint32_t stg_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stg;
+      const uint32_t wrow = stg_addr + (uint32_t)c * PATCH_SP;                               // my channel row (staging writes)
+      const uint32_t rrow = stg_addr + (uint32_t)(lane >> 3) * PATCH_SP + (lane & 7) * 16;   // read-back: row lane >> 3 (+ 8 it)
       patch_static_for<0, 2>([&](auto g_c) __attribute__((always_inline)) {
         constexpr int gi = decltype(g_c)::value;
         constexpr int nt0 = gi * 4, cnt = gi == 0 ? 4 : NTW - 4;
@@ -213,44 +235,76 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
           constexpr int t = decltype(t_c)::value;
           const v4i ch = NONNEG ? tr_requant_chunk<ACT_RELU>(acc[nt0 + t], s2, b2, leak, lo2, hi2)
                                 : tr_requant_chunk<ACT_LEAKY>(acc[nt0 + t], s2, b2, leak, lo2, hi2);
-          const uint32_t p = (uint32_t)(pw0 + 32 * (nt0 + t) + 16 * h);
+          const v2i pc0 = {ch[0], ch[1]}, pc1 = {ch[2], ch[3]};
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {  // two 8-pixel pieces, each inside one row (PWp % 8 == 0)
+          for (int k = 0; k < 4; ++k) {  // pixel order; lanes of half k >> 1 hold piece k
             int valid;
-            const int d = dst_of(p + 8 * e, valid, 8);
-            uint8_t* q = stg + c * PATCH_SP + (d - d_a);
-            const uint32_t v0 = (uint32_t)ch[2 * e], v1 = (uint32_t)ch[2 * e + 1];
-            if (valid == 8 && ((d - d_a) & 3) == 0) {
-              *reinterpret_cast<uint32_t*>(q) = v0;
-              *reinterpret_cast<uint32_t*>(q + 4) = v1;
-            } else if (valid > 0) {
-#pragma unroll
-              for (int k = 0; k < 8; ++k)
-                if (k < valid) q[k] = (uint8_t)((k < 4 ? v0 : v1) >> (8 * (k & 3)));
-            }
+            const int d = dst_of((uint32_t)(pw0 + 32 * (nt0 + t) + 8 * k), valid, 8);  // scalar
+            // a dropped piece goes to the spare 8 bytes at the end of the row (no branch: a pipeline bubble per piece)
+            const uint32_t wa_ = wrow + (uint32_t)(valid > 0 ? d - d_a : PATCH_SP - 8);
+            const unsigned long long m = (k >> 1) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+            if (k & 1) asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(wa_), "v"(pc1), "s"(m) : "memory");
+            else asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(wa_), "v"(pc0), "s"(m) : "memory");
           }
         });
         const int len = d_b - d_a;  // <= 128
+        if (diag && nepi == 0 && lane == 0) lstamp[18 + 2 * gi] = __builtin_amdgcn_s_memtime();  // group staged
+        v4i rv[4];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(rv[0]) : "v"(rrow) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rv[1]) : "v"(rrow), "n"(8 * PATCH_SP) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rv[2]) : "v"(rrow), "n"(16 * PATCH_SP) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rv[3]) : "v"(rrow), "n"(24 * PATCH_SP) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3])::"memory");
+        // whole 16-byte pieces, then the row's tail (len % 16 bytes, the same for every row: wave-uniform decisions)
+        const int off = (lane & 7) * 16, tail = len & 15, toff = len & ~15;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int row = it * 8 + (lane >> 3), off = (lane & 7) * 16;
-          const int m = mt * 32 + row;
-          if (off < len && m < a.M) {
-            const v4i v = *reinterpret_cast<const v4i*>(stg + row * PATCH_SP + off);
-            store_chunk_i8(yb + (size_t)m * (uint32_t)a.HWY + d_a + off, (uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3], 0, len - off);
+          const int m = mt * 32 + it * 8 + (lane >> 3);
+          int8_t* yp = yb + (size_t)m * (uint32_t)a.HWY + d_a + off;
+          const v4i v = rv[it];
+          if (off + 16 <= len && m < a.M) __builtin_memcpy(yp, &v, 16);  // possibly unaligned: fine for global memory
+          if (tail) {                                                     // wave-uniform
+            const bool mine = off == toff && m < a.M;
+            int tb = 0;  // bytes of the tail already stored
+            if (tail & 8) {
+              const v2i v8 = {v[0], v[1]};
+              if (mine) __builtin_memcpy(yp, &v8, 8);
+              tb = 8;
+            }
+            if (tail & 4) {
+              const int dw = tb ? v[2] : v[0];
+              if (mine) __builtin_memcpy(yp + tb, &dw, 4);
+              tb += 4;
+            }
+            if (tail & 3) {
+              const uint32_t dw = (uint32_t)(tb == 0 ? v[0] : (tb == 4 ? v[1] : (tb == 8 ? v[2] : v[3])));
+              if (tail & 2) {
+                const uint16_t hw16 = (uint16_t)dw;
+                if (mine) __builtin_memcpy(yp + tb, &hw16, 2);
+              }
+              if (tail & 1) {
+                const uint8_t b8 = (uint8_t)((tail & 2) ? dw >> 16 : dw);
+                if (mine) yp[tb + (tail & 2)] = (int8_t)b8;
+              }
+            }
           }
         }
+        if (diag && nepi == 0 && lane == 0) lstamp[19 + 2 * gi] = __builtin_amdgcn_s_memtime();  // group's stores issued
       });
     } else {
-      // 32-bit outputs: register group gq of n tile t = 4 consecutive pixels 32t + 8gq + 4h (inside one row: PWp % 4 == 0)
+      // 32-bit outputs: register group gq of n tile t = 4 consecutive pixels 32t + 8gq + 4h (inside one row: PWp % 4 == 0);
+      // the geometry of both halves' groups is computed on the scalar unit, the lane picks its half's
       const float fcap = a.act == ACT_RELU6 ? a.alpha : __builtin_huge_valf();
       const float flo_ = (a.act == ACT_RELU || a.act == ACT_RELU6) ? 0.f : -__builtin_huge_valf();
       patch_static_for<0, NTW>([&](auto t_c) __attribute__((always_inline)) {
         constexpr int t = decltype(t_c)::value;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          int valid;
-          const int d = dst_of((uint32_t)(pw0 + 32 * t + 8 * gq + 4 * h), valid, 4);
+          int v0_, v1_;
+          const int d0_ = dst_of((uint32_t)(pw0 + 32 * t + 8 * gq), v0_, 4);
+          const int d1_ = dst_of((uint32_t)(pw0 + 32 * t + 8 * gq + 4), v1_, 4);
+          if (v0_ == 0 && v1_ == 0) continue;  // wave-uniform
+          const int valid = h ? v1_ : v0_, d = h ? d1_ : d0_;
           if (valid == 0 || mrow >= a.M) continue;
           const size_t yoff = (size_t)b * a.y_bstride + (size_t)mrow * (uint32_t)a.HWY + d;
           if constexpr (OUT == OUT_I32) {
@@ -267,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
             float f[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float yv = __fmaf_rn((float)acc[t][4 * gq + e], sc, bi);
+              float yv = __fmaf_rn((float)acc[t][4 * gq + e], sc, bi_);
               if (a.act == ACT_LEAKY) yv = yv > 0.f ? yv : a.alpha * yv;  // kernel-uniform
               f[e] = fminf(fmaxf(yv, flo_), fcap);
             }
@@ -319,11 +373,24 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
   };
   // FIRST: 0 = not the first slab of a tile, 1 = the first (the accumulators start from the constant 0 operand), 2 = run
   // time (`first`: the accumulators are zeroed)
-  auto step = [&](auto ch_c, auto ss_c, auto first_c, bool first, bool active) __attribute__((always_inline)) {
+  // R0: the first round of the register-resident weights: the prologue interleaves their loads with the first D slabs, the
+  // wait of step q < D leaves everything behind fragment 3q + 2 in flight (see the prologue).
+  auto step = [&](auto ch_c, auto ss_c, auto first_c, bool r0, bool first, bool active) __attribute__((always_inline)) {
     constexpr int CH = decltype(ch_c)::value, SS = decltype(ss_c)::value, FIRST = decltype(first_c)::value;
-    // my pieces of this slab pair have landed (counted: everything issued after them may still fly) ...
-    constexpr int WAITN = (D - 1) * NPW;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    // my pieces of this slot have landed (counted: everything issued after them may still fly) ...
+    constexpr int Q = CH * 3 + SS;
+    constexpr int REG = (D - 1) * NPW;
+    constexpr int WAIT0 = (STAT && Q < D) ? (D - 1 - Q) * (NPW + 3) + (18 - 3 * D) + Q * NPW : REG;
+    static_assert(WAIT0 >= REG && WAIT0 < 64, "vmcnt");
+    if constexpr (STAT && Q < D) {
+      if (r0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT0) : "memory");  // block-uniform
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REG) : "memory");
+      asm volatile("" : "+v"(w[3 * Q]), "+v"(w[3 * Q + 1]), "+v"(w[3 * Q + 2]));  // no use of these fragments above the wait
+      if constexpr (Q == 0 && OUT != OUT_I32) asm volatile("" : "+v"(sc), "+v"(bi));  // (the two oldest loads)
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REG) : "memory");
+      if constexpr (STAT) asm volatile("" : "+v"(w[3 * Q]), "+v"(w[3 * Q + 1]), "+v"(w[3 * Q + 2]));
+    }
     __builtin_amdgcn_s_barrier();  // ... everyone's have, and nobody reads the previous step's slot any more
     if (diag && nstep < 6 && lane == 0) lstamp[5 + nstep] = __builtin_amdgcn_s_memtime();
     {
@@ -390,23 +457,27 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
   };
 
-  // ---- prologue: the slab pairs of the first D steps
+  // ---- prologue: the slots of the first D steps; register-resident weights: the three fragments of step p right behind
+  // slab p, the rest behind slab D - 1: step 0 starts when a quarter of the prologue's bytes has arrived
+  if (NH == 1 && a.delay > 0 && 2 * blockIdx.x >= gridDim.x) {  // the CU's second block starts late (see the template comment)
+    for (int i = 0; i < a.delay; i += 100) __builtin_amdgcn_s_sleep(100);
+  }
   cursor_tiles(0);
-  for (int p = 0; p < D; ++p) {
-    issue(iqc, iqs, p);
+  patch_static_for<0, D>([&](auto p_c) __attribute__((always_inline)) {
+    constexpr int pp = decltype(p_c)::value;
+    issue(iqc, iqs, pp);
     advance_cursor();
-  }
-  if constexpr (STAT) {
-    // every weight fragment (issued before the first DMA piece) has landed before an MFMA names it: vmcnt(D * NPW) leaves
-    // only the DMA pieces in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NPW) : "memory");
-    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]));
-    asm volatile("" : "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]), "+v"(w[16]), "+v"(w[17]));
-  }
+    if constexpr (STAT) {
+      load_w(std::integral_constant<int, 3 * pp>{});
+      load_w(std::integral_constant<int, 3 * pp + 1>{});
+      load_w(std::integral_constant<int, 3 * pp + 2>{});
+    }
+  });
+  if constexpr (STAT) patch_static_for<3 * D, 18>([&](auto i_c) __attribute__((always_inline)) { load_w(i_c); });
   PLHIP_PATCH_STAMP(3);
 
   using std::integral_constant;
-  int nstamp = 17;  // 5-10: barrier of step i passed, 11-16: its MFMAs issued, 17..: end of round k (epilogue instructions issued)
+  int nstamp = 22;  // 5-10: barrier of step i passed, 11-16: its MFMAs issued, 18-21: first epilogue, 22..: end of round k
   for (int k = 0; k < a.rounds; ++k) {
     const int t = k * S + sig;
     const bool active = t < a.T;                                   // wave-uniform
@@ -417,18 +488,23 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
       typedef integral_constant<int, 0> I0;
       typedef integral_constant<int, 1> I1;
       typedef integral_constant<int, 2> I2;
-      step(I0{}, I0{}, I1{}, false, active);
-      step(I0{}, I1{}, I0{}, false, active);
-      step(I0{}, I2{}, I0{}, false, active);
-      step(I1{}, I0{}, I0{}, false, active);
-      step(I1{}, I1{}, I0{}, false, active);
-      step(I1{}, I2{}, I0{}, false, active);
+      const bool r0 = k == 0;
+      step(I0{}, I0{}, I1{}, r0, false, active);
+      step(I0{}, I1{}, I0{}, r0, false, active);
+      step(I0{}, I2{}, I0{}, r0, false, active);
+      step(I1{}, I0{}, I0{}, r0, false, active);
+      step(I1{}, I1{}, I0{}, r0, false, active);
+      step(I1{}, I2{}, I0{}, r0, false, active);
     } else {
+      if (k == 0 && OUT != OUT_I32) {  // scale / bias: older than every DMA piece, so long landed at the first epilogue
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NPW) : "memory");
+        asm volatile("" : "+v"(sc), "+v"(bi));
+      }
       for (int ic = 0; ic < NCH; ++ic) {
         typedef integral_constant<int, -1> IR;
-        step(IR{}, integral_constant<int, 0>{}, integral_constant<int, 2>{}, ic == 0, active);
-        step(IR{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, false, active);
-        step(IR{}, integral_constant<int, 2>{}, integral_constant<int, 0>{}, false, active);
+        step(IR{}, integral_constant<int, 0>{}, integral_constant<int, 2>{}, false, ic == 0, active);
+        step(IR{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, false, false, active);
+        step(IR{}, integral_constant<int, 2>{}, integral_constant<int, 0>{}, false, false, active);
       }
     }
     if (active) {
@@ -437,6 +513,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
       int be = b, pe = p0, me = mt;
       asm volatile("" : "+s"(be), "+s"(pe), "+s"(me));
       epilogue(be, pe, me);
+      ++nepi;
     }
     if (nstamp < PATCH_STAMP_SLOTS - 3) {
       PLHIP_PATCH_STAMP(nstamp);
@@ -454,27 +531,27 @@ __global__ __launch_bounds__(512, 2) void conv_patch_i8_kernel(PatchArgs a) {
   }
 }
 
-template <int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT>
+template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT>
 static inline void launch_patch_t(const PatchArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)NSLOT * (2 * 32 * a.pitch + (STAT ? 0 : 3 * WMH * 1024));
+  const size_t lds = (size_t)NSLOT * (NH * 32 * a.pitch + (STAT ? 0 : 3 * WMH * 1024));
   const unsigned blocks = (unsigned)(8 * a.MB * a.NQ);
   const bool nonneg = a.act == ACT_RELU || a.act == ACT_RELU6;
   if (OUT == OUT_I8 && !nonneg) {
-    auto kfn = conv_patch_i8_kernel<WMH, WNH, NPW, NSLOT, STAT, OUT, false>;
+    auto kfn = conv_patch_i8_kernel<NH, WMH, WNH, NPW, NSLOT, STAT, OUT, false>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256 * NH), lds, s, a);
   } else {
-    auto kfn = conv_patch_i8_kernel<WMH, WNH, NPW, NSLOT, STAT, OUT, true>;
+    auto kfn = conv_patch_i8_kernel<NH, WMH, WNH, NPW, NSLOT, STAT, OUT, true>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256 * NH), lds, s, a);
   }
 }
 
-template <int WMH, int WNH, int NPW, int NSLOT, bool STAT>
+template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT>
 static inline void launch_patch_o(const PatchArgs& a, int out, hipStream_t s) {
-  if (out == OUT_I32) launch_patch_t<WMH, WNH, NPW, NSLOT, STAT, OUT_I32>(a, s);
-  else if (out == OUT_F32) launch_patch_t<WMH, WNH, NPW, NSLOT, STAT, OUT_F32>(a, s);
-  else launch_patch_t<WMH, WNH, NPW, NSLOT, STAT, OUT_I8>(a, s);
+  if (out == OUT_I32) launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_I32>(a, s);
+  else if (out == OUT_F32) launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_F32>(a, s);
+  else launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_I8>(a, s);
 }
 
 }  // namespace plhip

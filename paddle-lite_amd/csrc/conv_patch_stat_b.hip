@@ -3,5 +3,5 @@
 #include "conv_patch_kernel.h"
 
 namespace plhip {
-void launch_patch_stat_b(const PatchArgs& a, int out, hipStream_t s) { launch_patch_o<2, 2, 5, 3, true>(a, out, s); }
+void launch_patch_stat_b(const PatchArgs& a, int out, hipStream_t s) { launch_patch_o<1, 2, 2, 5, 3, true>(a, out, s); }
 }  // namespace plhip

@@ -3,5 +3,5 @@
 #include "conv_patch_kernel.h"
 
 namespace plhip {
-void launch_patch_stream_a(const PatchArgs& a, int out, hipStream_t s) { launch_patch_o<4, 1, 5, 3, false>(a, out, s); }
+void launch_patch_stream_a(const PatchArgs& a, int out, hipStream_t s) { launch_patch_o<2, 4, 1, 5, 3, false>(a, out, s); }
 }  // namespace plhip

@@ -77,7 +77,7 @@ static void padded_dims(const plhip_conv_desc* d, int* ph, int* pw) {
 static size_t patch_input_bytes(const plhip_conv_desc* d) {
   const int pwp = plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3]);
   const size_t b = (size_t)d->n * d->cin * (d->h + d->pad[0] + d->pad[1]) * pwp;
-  return ((b + 3) & ~(size_t)3) + 4096;
+  return ((b + 15) & ~(size_t)15) + 4096;
 }
 static size_t padded_input_bytes(const plhip_conv_desc* d) {  // + slack: the last 16-byte pieces run past the last row
   int ph, pw;
@@ -380,8 +380,8 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
   }
   if (g.impl == IMPL_PATCH_GEMM) {
     const size_t need = patch_input_bytes(d);
-    if (!workspace || workspace_bytes < need || !aligned(workspace, 4))
-      return fail(ctx, PLHIP_ERR_WORKSPACE, "plhip_conv2d_int8: padded-input workspace missing, too small or unaligned");
+    if (!workspace || workspace_bytes < need || !aligned(workspace, 16))
+      return fail(ctx, PLHIP_ERR_WORKSPACE, "plhip_conv2d_int8: padded-input workspace missing, too small or unaligned (16 bytes)");
     const int PWp = plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3]), PH = d->h + d->pad[0] + d->pad[1];
     plhip::PadArgs pa;
     pa.stride = 1;
@@ -390,8 +390,8 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     pa.planes = d->n * d->cin;
     pa.h = d->h; pa.w = d->w; pa.ph = PH; pa.pw = PWp; pa.pt = d->pad[0]; pa.pl = d->pad[2];
     pa.total = (long)need;
-    plhip::launch_pad_input(pa, ctx->stream);
-    LAUNCHCHK(ctx, "pad_input");
+    plhip::launch_pad_rows8(pa, ctx->stream);
+    LAUNCHCHK(ctx, "pad_rows8");
     plhip::PatchArgs a;
     memset(&a, 0, sizeof(a));
     a.xp = (const int8_t*)workspace;

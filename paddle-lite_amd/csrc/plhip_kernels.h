@@ -57,6 +57,7 @@ struct PadArgs {
   int div_plane_s, div_pw_s, div_pwq_s, div_ph_s;
 };
 void launch_pad_input(const PadArgs& a, hipStream_t s);
+void launch_pad_rows8(PadArgs a, hipStream_t s);  // conv_patch_i8.hip: rows of pw % 8 == 0 bytes, 16 bytes per thread
 
 // dense 3x3 stride-1 convolution on input patches (conv_patch_i8.hip)
 struct PatchArgs {
@@ -83,6 +84,7 @@ struct PatchArgs {
   int8_t* y2;
   float inv_scale2;
   int dbg;
+  int delay;           // NH = 1: s_sleep units the second block of a CU starts late (experiments)
   unsigned long long* stamps;
 };
 // row pitch of the padded copy for (w, pl, pr), 0 = outside the route

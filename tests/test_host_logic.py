@@ -41,7 +41,7 @@ def test_descriptor_helpers(pkg):
     assert lib.plhip_conv_packed_weight_bytes(ctypes.byref(d)) == 4 * 18 * 1024
     # C2 runs on the patch kernel (3x3 s1, Cin % 32 == 0): the workspace is the zero-padded input copy with rows of 64 bytes
     # (58 rounded up to a multiple of 8) + slack, not the im2col buffer; the packed weights keep their size (tap-major order)
-    assert lib.plhip_conv_workspace_bytes(ctypes.byref(d)) == 32 * 64 * 58 * 64 + 4096
+    assert lib.plhip_conv_workspace_bytes(ctypes.byref(d)) == 32 * 64 * 58 * 64 + 4096  # (a multiple of 16)
     assert lib.plhip_conv_impl_name(ctypes.byref(d)) == b"conv_patch_gemm_int8_mfma32x32x32"
     # 3x3 with a channel tail (Cin % 32 != 0) stays on the ring kernel's implicit GEMM: 58 x 58 planes + slack
     d48 = capi.conv_desc(32, 48, 56, 56, 128, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Static check of the wide-tile GEMM kernels (csrc/gemm_wide_kernel.h, instantiated by gemm_wide_n4/n7/n8.hip).
+"""Static check of the wide-tile GEMM kernels (csrc/gemm_wide_kernel.h, instantiated by gemm_wide_n4/n7/n8.hip) and of the
+patch convolution kernels (csrc/conv_patch_kernel.h, instantiated by conv_patch_i8 / _stat_b / _stream.hip).
 
 They fetch the weight fragments with inline-asm `global_load_dwordx4` and the activation fragments with inline-asm
 `ds_read_b64_tr_b8`, neither of which the compiler's wait-count pass sees, and wait for them with hand-counted
@@ -22,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "paddle-lite_amd", "csrc")
 REG = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
 VM_OPS = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "flat_load", "flat_store", "scratch_")
-KERN = re.compile(r"^(_ZN5plhip19gemm_i8_wide_kernelI\w+EvNS_8GemmArgsE):")
+KERN = re.compile(r"^(_ZN5plhip19gemm_i8_wide_kernelI\w+EvNS_8GemmArgsE|_ZN5plhip20conv_patch_i8_kernelI\w+EvNS_9PatchArgsE):")
+UNITS = ("gemm_wide_n4", "gemm_wide_n7", "gemm_wide_n8", "conv_patch_i8", "conv_patch_stat_b", "conv_patch_stream")
 
 
 def regs(tok):
@@ -38,6 +40,9 @@ def regs(tok):
 def check_kernel(name, lines):
     vm, lgkm = [], []  # outstanding operations in issue order: (line, set of destination registers of an ASM load, or empty)
     errs, n_w, n_f, in_asm = [], 0, 0, False
+    # `if (first round) s_waitcnt vmcnt(A) else s_waitcnt vmcnt(B)` (conv_patch_kernel.h) reads, in this linear walk, as two
+    # waits in a row with only branches / labels between them: they are alternatives, the walk applies the WEAKER one
+    pending_vm = None  # (count, [ops issued since]) of an asm vmcnt wait not applied yet
     for ln, raw in lines:
         if "#ASMSTART" in raw:
             in_asm = True
@@ -51,9 +56,14 @@ def check_kernel(name, lines):
         parts = ins.split(None, 1)
         op = parts[0]
         ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        if pending_vm is not None and not (op == "s_waitcnt" and in_asm) and not op.startswith(("s_cbranch", "s_branch")):
+            del vm[:max(0, len(vm) - pending_vm)]
+            pending_vm = None
         if op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", ins)
-            if m:
+            if m and in_asm and "lgkmcnt" not in ins:
+                pending_vm = int(m.group(1)) if pending_vm is None else max(pending_vm, int(m.group(1)))
+            elif m:
                 del vm[:max(0, len(vm) - int(m.group(1)))]
             m = re.search(r"lgkmcnt\((\d+)\)", ins)
             if m:
@@ -71,11 +81,11 @@ def check_kernel(name, lines):
         if hit:
             errs.append("%s:%d `%s` touches v%s while an inline-asm load into it may be in flight" % (name[:60], ln, ins[:70], sorted(hit)[:4]))
         if op.startswith(VM_OPS):
-            dst = regs(ops[0]) if (in_asm and op.startswith("global_load_dwordx4") and "lds" not in op) else set()
+            dst = regs(ops[0]) if (in_asm and op.startswith(("global_load_dwordx4", "global_load_dword")) and "lds" not in op) else set()
             n_w += bool(dst)
             vm.append((ln, dst))
         elif op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load"):
-            dst = regs(ops[0]) if (in_asm and op == "ds_read_b64_tr_b8") else set()
+            dst = regs(ops[0]) if (in_asm and op in ("ds_read_b64_tr_b8", "ds_read_b128")) else set()
             n_f += bool(dst)
             lgkm.append((ln, dst))
     return n_w, n_f, errs
@@ -85,12 +95,12 @@ def main():
     files = [a for a in sys.argv[1:] if a.endswith(".s")]
     if "--asm-dir" in sys.argv:
         d = sys.argv[sys.argv.index("--asm-dir") + 1]
-        files = [os.path.join(d, n + "-hip-amdgcn-amd-amdhsa-gfx950.s") for n in ("gemm_wide_n4", "gemm_wide_n7", "gemm_wide_n8")]
+        files = [os.path.join(d, n + "-hip-amdgcn-amd-amdhsa-gfx950.s") for n in UNITS]
         files = [f for f in files if os.path.exists(f)]
     tmp = None
     if not files:
         tmp = tempfile.TemporaryDirectory()
-        for n in ("gemm_wide_n4", "gemm_wide_n7", "gemm_wide_n8"):
+        for n in UNITS:
             out = os.path.join(tmp.name, n + ".s")
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm",
                                    "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", "-I", CSRC, "-o", out,
@@ -115,7 +125,7 @@ def main():
                     cur = None
     for e in total[:40]:
         print("  ", e)
-    print("%d wide-tile kernels checked, %d problems" % (nk, len(total)))
+    print("%d wide-tile / patch kernels checked, %d problems" % (nk, len(total)))
     return 1 if total or nk == 0 else 0
 
 

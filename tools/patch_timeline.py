@@ -50,10 +50,12 @@ def main():
         st = st[st[:, 0, 1] != 0]
         print("%s n%d %d->%d @%d: blocks with stamps: %d" % (L.plhip_conv_impl_name(C.byref(d)).decode(), n, cin, cout, hw, st.shape[0]))
         rt0, rt1 = st[:, 0, 0], st[:, :, 31].max(axis=1)
+        print('blocks x waves:', st.shape[0], int((st[0, :, 1] != 0).sum()))
         print("kernel span %.2f us; block starts p50 %.2f max %.2f us; block lifetime p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (
             (rt1.max() - rt0.min()) / 100.0, np.median(rt0 - rt0.min()) / 100.0, (rt0.max() - rt0.min()) / 100.0,
             *np.percentile((rt1 - rt0) / 100.0, [10, 50, 90, 100])))
         t = st.reshape(-1, SLOTS)
+        t = t[t[:, 1] != 0]  # (4-wave blocks leave the rows of waves 4-7 empty)
 
         def show(label, v):
             print("  %-44s cyc p10 %7.0f  p50 %7.0f  p90 %7.0f" % ((label,) + tuple(np.percentile(v, [10, 50, 90]))))
@@ -64,13 +66,39 @@ def main():
             show("step %d: barrier -> MFMAs issued" % i, t[:, 11 + i] - t[:, 5 + i])
             if i < 5:
                 show("step %d end -> barrier of step %d passed" % (i, i + 1), t[:, 6 + i] - t[:, 11 + i])
+        show("step 5 MFMAs -> epilogue group 0 staged", t[:, 18] - t[:, 16])
+        show("  -> its stores issued", t[:, 19] - t[:, 18])
+        show("  -> group 1 staged", t[:, 20] - t[:, 19])
+        show("  -> its stores issued", t[:, 21] - t[:, 20])
         show("whole wave", t[:, 30] - t[:, 1])
-        rounds = [i for i in range(17, 30) if (t[:, i] != 0).all()]
+        nr = int(os.environ.get("ROUNDS", "1"))
+        rounds = list(range(22, min(30, 22 + nr)))
         prev = t[:, 1]
         for i in rounds:
-            show("-> end of round %d" % (i - 17), t[:, i] - prev)
+            show("-> end of round %d" % (i - 22), t[:, i] - prev)
             prev = t[:, i]
         show("last round end -> exit (drain)", t[:, 30] - prev)
+        # blocks that shared a CU (HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID): start offsets and the offset of
+        # their first epilogues, in cycles
+        w0 = st[:, 0, :]
+        hw = w0[:, 2] & 0xffffffff
+        key = ((w0[:, 2] >> 32) & 0xf) * 4096 + ((hw >> 8) & 0xff)
+        from collections import defaultdict
+        groups = defaultdict(list)
+        for i, k in enumerate(key):
+            groups[int(k)].append(i)
+        sizes = np.array([len(v) for v in groups.values()])
+        print("  CUs used %d, blocks per CU min %d max %d" % (len(groups), sizes.min(), sizes.max()))
+        offs, eoffs, ids = [], [], []
+        for v in groups.values():
+            if len(v) == 2:
+                a0, b0 = v
+                offs.append(abs(int(w0[a0, 0]) - int(w0[b0, 0])) * (np.median((t[:, 30] - t[:, 1]) / np.maximum(1, (t[:, 31] - t[:, 0])))))
+                eoffs.append(abs((int(w0[a0, 18]) - int(w0[a0, 1])) - (int(w0[b0, 18]) - int(w0[b0, 1]))))
+                ids.append(abs(a0 - b0))
+        if offs:
+            print("  CU partners: block index distance p50 %d; start offset p50 %.0f cycles; first-epilogue offset (rel. to own start) p10 %.0f p50 %.0f p90 %.0f cycles" % (
+                np.median(ids), np.median(offs), *np.percentile(eoffs, [10, 50, 90])))
         clk = (t[:, 30] - t[:, 1]) / np.maximum(1, (t[:, 31] - t[:, 0])) * 100.0
         print("  shader clock p50 %.0f MHz" % np.median(clk))
 
