@@ -155,25 +155,29 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
       cb[hf] = reinterpret_cast<const uint8_t*>(a.xp) + (size_t)b * a.C * (uint32_t)a.PLANE + p0;
     }
   };
-  auto issue = [&](int ic, int is, int slot) __attribute__((always_inline)) {
-    const size_t coff = (size_t)(ic * 32) * (uint32_t)a.PLANE + is;
+  // one DMA piece j of the slot (chunk ic, shift is) -> ring slot `slot`; j < NPA: activations, then weights
+  auto issue_piece = [&](auto j_c, int ic, int is, int slot) __attribute__((always_inline)) {
+    constexpr int j = decltype(j_c)::value;
     uint8_t* sb = ring + slot * SLOTB;
-    uint32_t ln = (uint32_t)lane;
-    if constexpr (!PVO_KEPT) asm volatile("" : "+v"(ln));  // (opaque: not hoisted back out of the loop)
-#pragma unroll
-    for (int j = 0; j < NPA; ++j) {
+    if constexpr (j < NPA) {
+      const size_t coff = (size_t)(ic * 32) * (uint32_t)a.PLANE + is;
       const uint8_t* sbase = (NH == 2 && pai[j] >= a.pps ? cb[NH - 1] : cb[0]) + coff;  // wave-uniform
       uint32_t vo;
-      if constexpr (PVO_KEPT) vo = pvo[j];
-      else vo = piece_offset(pai[j], ln);
+      if constexpr (PVO_KEPT) {
+        vo = pvo[j];
+      } else {
+        uint32_t ln = (uint32_t)lane;
+        asm volatile("" : "+v"(ln));  // (opaque: not hoisted back out of the loop)
+        vo = piece_offset(pai[j], ln);
+      }
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(sbase + vo), (lds_ptr_t)(sb + pai[j] * 1024), 16, 0, 0);
-    }
-    if constexpr (!STAT) {
+    } else {
       const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.wp) + (size_t)(ic * 9 + is * 3) * 1024;
-#pragma unroll
-      for (int j = 0; j < NPW - NPA; ++j)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + pwoff[j] + lane16), (lds_ptr_t)(sb + NH * SLAB + pwi[j] * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + pwoff[j - NPA] + lane16), (lds_ptr_t)(sb + NH * SLAB + pwi[j - NPA] * 1024), 16, 0, 0);
     }
+  };
+  auto issue = [&](int ic, int is, int slot) __attribute__((always_inline)) {
+    patch_static_for<0, NPW>([&](auto j_c) __attribute__((always_inline)) { issue_piece(j_c, ic, is, slot); });
   };
 
   // ---- fragment addresses: lane 2q'+p of a 16-lane group -> channel row q', 8-byte sub-chunk p; group parity -> 16-pixel
@@ -375,7 +379,8 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   // time (`first`: the accumulators are zeroed)
   // R0: the first round of the register-resident weights: the prologue interleaves their loads with the first D slabs, the
   // wait of step q < D leaves everything behind fragment 3q + 2 in flight (see the prologue).
-  auto step = [&](auto ch_c, auto ss_c, auto first_c, bool r0, bool first, bool active) __attribute__((always_inline)) {
+  auto step = [&](auto ch_c, auto ss_c, auto first_c, bool r0, bool first) __attribute__((always_inline)) {
+    using std::integral_constant;
     constexpr int CH = decltype(ch_c)::value, SS = decltype(ss_c)::value, FIRST = decltype(first_c)::value;
     // my pieces of this slot have landed (counted: everything issued after them may still fly) ...
     constexpr int Q = CH * 3 + SS;
@@ -393,14 +398,16 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     }
     __builtin_amdgcn_s_barrier();  // ... everyone's have, and nobody reads the previous step's slot any more
     if (diag && nstep < 6 && lane == 0) lstamp[5 + nstep] = __builtin_amdgcn_s_memtime();
-    {
-      int islot = slot + D;
-      islot = islot >= NSLOT ? islot - NSLOT : islot;
-      issue(iqc, iqs, islot);
-      advance_cursor();
-    }
+    // The slot of the step before is free now: the DMA of the slot D steps ahead goes into it, ONE PIECE BEHIND EVERY FOURTH
+    // MFMA.  (All pieces at the top of the step, from all waves at once, is a burst of 24-40 KiB into an address path that
+    // takes ~58 B/clk: every wave sat ~700 cycles in the issue with the matrix pipe idle, and the time of the data movement
+    // ADDED to the MFMA time instead of hiding under it: profiles/r03_patch_decompose.txt.)
+    int islot = slot + D;
+    islot = islot >= NSLOT ? islot - NSLOT : islot;
+    const int qc = iqc, qs = iqs;
+    advance_cursor();
     const uint32_t sb = (uint32_t)(slot * SLOTB);
-    if (active) {
+    {  // (an idle stream, past the last tile, multiplies the clamped tile's bytes again: no branch around the loop)
       if (FIRST == 2 && first) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
@@ -448,9 +455,11 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i + 3 < NM) PLHIP_PATCH_READ(i + 3);
+        if constexpr (i % 4 == 1 && i / 4 < NPW) issue_piece(integral_constant<int, i / 4>{}, qc, qs, islot);
         __builtin_amdgcn_sched_barrier(0);
       });
 #undef PLHIP_PATCH_READ
+      static_assert(4 * (NPW - 1) + 1 < NM, "every piece has its MFMA");
     }
     if (diag && nstep < 6 && lane == 0) lstamp[11 + nstep] = __builtin_amdgcn_s_memtime();
     ++nstep;
@@ -480,8 +489,8 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   int nstamp = 22;  // 5-10: barrier of step i passed, 11-16: its MFMAs issued, 18-21: first epilogue, 22..: end of round k
   for (int k = 0; k < a.rounds; ++k) {
     const int t = k * S + sig;
-    const bool active = t < a.T;                                   // wave-uniform
-    const int tc = active ? t : a.T - 1;
+    const bool live = t < a.T;                                     // wave-uniform
+    const int tc = live ? t : a.T - 1;
     const int b = (int)fastdiv_u31((uint32_t)tc, a.tpi_m, a.tpi_s);
     const int p0 = (tc - b * a.TPI) * NTH;
     if constexpr (STAT) {
@@ -489,12 +498,12 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
       typedef integral_constant<int, 1> I1;
       typedef integral_constant<int, 2> I2;
       const bool r0 = k == 0;
-      step(I0{}, I0{}, I1{}, r0, false, active);
-      step(I0{}, I1{}, I0{}, r0, false, active);
-      step(I0{}, I2{}, I0{}, r0, false, active);
-      step(I1{}, I0{}, I0{}, r0, false, active);
-      step(I1{}, I1{}, I0{}, r0, false, active);
-      step(I1{}, I2{}, I0{}, r0, false, active);
+      step(I0{}, I0{}, I1{}, r0, false);
+      step(I0{}, I1{}, I0{}, r0, false);
+      step(I0{}, I2{}, I0{}, r0, false);
+      step(I1{}, I0{}, I0{}, r0, false);
+      step(I1{}, I1{}, I0{}, r0, false);
+      step(I1{}, I2{}, I0{}, r0, false);
     } else {
       if (k == 0 && OUT != OUT_I32) {  // scale / bias: older than every DMA piece, so long landed at the first epilogue
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NPW) : "memory");
@@ -502,12 +511,12 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
       }
       for (int ic = 0; ic < NCH; ++ic) {
         typedef integral_constant<int, -1> IR;
-        step(IR{}, integral_constant<int, 0>{}, integral_constant<int, 2>{}, false, ic == 0, active);
-        step(IR{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, false, false, active);
-        step(IR{}, integral_constant<int, 2>{}, integral_constant<int, 0>{}, false, false, active);
+        step(IR{}, integral_constant<int, 0>{}, integral_constant<int, 2>{}, false, ic == 0);
+        step(IR{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, false, false);
+        step(IR{}, integral_constant<int, 2>{}, integral_constant<int, 0>{}, false, false);
       }
     }
-    if (active) {
+    if (live && !(a.dbg & 1)) {  // (PLHIP_GEMM_DEBUG & 1: no epilogue; timing experiments)
       // (opaque copies: the address arithmetic of the epilogue must not be hoisted above the K loop, where its lane masks
       // and offsets would sit in registers for the whole tile)
       int be = b, pe = p0, me = mt;

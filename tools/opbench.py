@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-op micro-benchmark through the C ABI (device-resident buffers, HIP events on the ctx stream).
-Usage: python tools/opbench.py [pw|dw|conv1|all] [--batch 128] [--reps 30]
-Prints one line per MobileNetV1 layer: time, algorithmic GB/s, TOP/s."""
+Usage: python tools/opbench.py [pw|dw|conv1|all] [--batch 128] [--reps 30] [--net mobilenet_v1|dw5x5|resnet50_3x3]
+Prints one line per layer: time, algorithmic GB/s, TOP/s.  --net dw5x5: depthwise 5x5 stride 1 / 2 planes (the shapes of
+lite/tests/math/conv_int8_compute_test.cc's 5x5 depthwise sweep at network sizes); --net resnet50_3x3: BASELINE config #2
+(at its own batch 32) and ResNet50's dense 3x3 layers."""
 import argparse
 import ctypes as C
 import os
@@ -42,16 +44,28 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--f32", action="store_true", help="fp32 output instead of int8")
+    ap.add_argument("--net", default="mobilenet_v1")
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     B = args.batch
     tot = 0.0
     with capi.Context(0) as ctx:
         L = ctx.L
-        for (name, op, cin, cout, k, s, p, g, hin) in wl.mobilenet_v1_layers():
-            kind = "conv1" if name == "conv1" else ("dw" if g > 1 else "pw")
+        if args.net == "dw5x5":
+            layers = [("dw5_%d_%d_s%d" % (c, h, st), "depthwise_conv2d", c, c, 5, st, 2, c, h)
+                      for (c, h, st) in [(32, 112, 1), (64, 112, 2), (128, 56, 1), (128, 56, 2), (256, 28, 1), (256, 28, 2), (512, 14, 1),
+                                         (512, 14, 2), (1024, 7, 1)]]
+        elif args.net == "resnet50_3x3":
+            layers = [("c2", "conv2d", 64, 128, 3, 1, 1, 1, 56), ("res2", "conv2d", 64, 64, 3, 1, 1, 1, 56), ("res3", "conv2d", 128, 128, 3, 1, 1, 1, 28),
+                      ("res4", "conv2d", 256, 256, 3, 1, 1, 1, 14), ("res5", "conv2d", 512, 512, 3, 1, 1, 1, 7), ("res3a", "conv2d", 128, 128, 3, 2, 1, 1, 56),
+                      ("res4a", "conv2d", 256, 256, 3, 2, 1, 1, 28), ("res5a", "conv2d", 512, 512, 3, 2, 1, 1, 14)]
+        else:
+            layers = wl.mobilenet_v1_layers()
+        for (name, op, cin, cout, k, s, p, g, hin) in layers:
+            kind = "conv1" if name == "conv1" else ("dw" if g > 1 else ("pw" if k == 1 else "conv"))
             if args.what not in ("all", kind, name):
                 continue
+            B = 32 if name == "c2" else args.batch
             ho = (hin + 2 * p - k) // s + 1
             d = capi.conv_desc(B, cin, hin, hin, cout, k, k, (p, p, p, p), (s, s), (1, 1), g, capi.ACT_RELU, 0.0)
             x = rng.integers(-127, 128, (B, cin, hin, hin), dtype=np.int8)
@@ -79,7 +93,7 @@ def main():
                 L.plhip_conv_impl_name(C.byref(d)).decode() if g == 1 else "depthwise"), flush=True)
             for q in list(ctx._allocs):
                 ctx.free(q)
-    if args.what in ("fused", "all"):
+    if args.what in ("fused", "all") and args.net == "mobilenet_v1":
         ftot = 0.0
         with capi.Context(0) as ctx:
             L = ctx.L
