@@ -156,12 +156,12 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     }
   };
   // one DMA piece j of the slot (chunk ic, shift is) -> ring slot `slot`; j < NPA: activations, then weights
-  auto issue_piece = [&](auto j_c, int ic, int is, int slot) __attribute__((always_inline)) {
+  auto issue_piece = [&](auto j_c, const uint8_t* const (&tb)[NH], int ic, int is, int slot) __attribute__((always_inline)) {
     constexpr int j = decltype(j_c)::value;
     uint8_t* sb = ring + slot * SLOTB;
     if constexpr (j < NPA) {
       const size_t coff = (size_t)(ic * 32) * (uint32_t)a.PLANE + is;
-      const uint8_t* sbase = (NH == 2 && pai[j] >= a.pps ? cb[NH - 1] : cb[0]) + coff;  // wave-uniform
+      const uint8_t* sbase = (NH == 2 && pai[j] >= a.pps ? tb[NH - 1] : tb[0]) + coff;  // wave-uniform
       uint32_t vo;
       if constexpr (PVO_KEPT) {
         vo = pvo[j];
@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     }
   };
   auto issue = [&](int ic, int is, int slot) __attribute__((always_inline)) {
-    patch_static_for<0, NPW>([&](auto j_c) __attribute__((always_inline)) { issue_piece(j_c, ic, is, slot); });
+    const uint8_t* tb[NH];
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) tb[hf] = cb[hf];
+    patch_static_for<0, NPW>([&](auto j_c) __attribute__((always_inline)) { issue_piece(j_c, tb, ic, is, slot); });
   };
 
   // ---- fragment addresses: lane 2q'+p of a 16-lane group -> channel row q', 8-byte sub-chunk p; group parity -> 16-pixel
@@ -405,6 +408,9 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     int islot = slot + D;
     islot = islot >= NSLOT ? islot - NSLOT : islot;
     const int qc = iqc, qs = iqs;
+    const uint8_t* qb[NH];  // (the cursor's tile bases BEFORE it advances: the last slot of a round still belongs to the old tile)
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) qb[hf] = cb[hf];
     advance_cursor();
     const uint32_t sb = (uint32_t)(slot * SLOTB);
     {  // (an idle stream, past the last tile, multiplies the clamped tile's bytes again: no branch around the loop)
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i + 3 < NM) PLHIP_PATCH_READ(i + 3);
-        if constexpr (i % 4 == 1 && i / 4 < NPW) issue_piece(integral_constant<int, i / 4>{}, qc, qs, islot);
+        if constexpr (i % 4 == 1 && i / 4 < NPW) issue_piece(integral_constant<int, i / 4>{}, qb, qc, qs, islot);
         __builtin_amdgcn_sched_barrier(0);
       });
 #undef PLHIP_PATCH_READ

@@ -332,7 +332,10 @@ def test_patch_conv_route(gpu_ctx, pkg, plref):
         (2, 64, 20, 20, 128, (1, 1, 1, 1), 1), (1, 64, 56, 56, 128, (1, 1, 1, 1), 2), (2, 64, 56, 56, 64, (1, 1, 1, 1), 1),
         (3, 64, 9, 15, 40, (1, 1, 1, 1), 0), (2, 64, 13, 27, 100, (0, 2, 2, 0), 4), (2, 128, 28, 28, 128, (1, 1, 1, 1), 1),
         (2, 256, 14, 14, 256, (1, 1, 1, 1), 1), (1, 96, 17, 33, 200, (1, 0, 0, 1), 2), (5, 160, 14, 14, 72, (0, 0, 0, 0), 0),
-        (37, 64, 14, 14, 96, (1, 1, 1, 1), 1), (1, 64, 40, 58, 130, (1, 1, 1, 1), 4)]
+        (37, 64, 14, 14, 96, (1, 1, 1, 1), 1), (1, 64, 40, 58, 130, (1, 1, 1, 1), 4),
+        # more tiles than tile streams (512): every stream works through two tiles (the ring, the DMA cursor and the
+        # register-resident weights across a tile boundary), in each of the three kernel variants
+        (530, 64, 6, 14, 96, (1, 1, 1, 1), 1), (530, 64, 6, 14, 32, (1, 1, 1, 1), 2), (530, 128, 6, 14, 72, (1, 1, 1, 1), 0)]
     for (n, cin, h, w, cout, pads, act) in cases:
         d = capi.conv_desc(n, cin, h, w, cout, 3, 3, pads, (1, 1), (1, 1), 1, act, 0.0)
         assert gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) == b"conv_patch_gemm_int8_mfma32x32x32", (cin, cout, w, pads)
