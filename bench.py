@@ -611,14 +611,17 @@ def main():
             # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script: FETCH_SIZE x2 per the gfx950 correction
             # + WRITE_SIZE); a file, not a live counter -> named in traffic_source, null when absent for this config
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", {"c3": "pmc_traffic.json", "c4": "pmc_traffic_c4.json"}.get(args.config, "none"))
+            tpath = os.path.join(ROOT, "profiles", {"c3": "pmc_traffic.json", "c4": "pmc_traffic_c4.json", "c2": "pmc_traffic_c2.json"}.get(args.config, "none"))
             if os.path.exists(tpath) and rows == cfg["batch"]:
                 try:
                     tj = json.load(open(tpath))
                     t_ = tj.get(dom)
+                    if not t_ and dom == "conv3x3" and "conv3x3_patch" in tj:  # one conv = the padded copy + the patch kernel
+                        t_ = {k_: tj["conv3x3_patch"][k_] + tj.get("conv3x3_patch_pad", {}).get(k_, 0.0)
+                              for k_ in ("fetch_bytes_per_launch_x2", "write_bytes_per_launch")}
                     if t_:
                         traffic = round(t_["fetch_bytes_per_launch_x2"] + t_["write_bytes_per_launch"])
-                        tsrc = "profiles/pmc_traffic.json @ %s (not measured in this run)" % tj.get("commit", "round 1")
+                        tsrc = "profiles/%s @ %s (not measured in this run)" % (os.path.basename(tpath), tj.get("commit", "round 1"))
                 except Exception:  # noqa: BLE001
                     traffic = None
             roof = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",

@@ -22,6 +22,10 @@ echo "pmc c3 done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_c4 -o f --output-format csv -- python $R/bench.py --config c4 $B --inflight 1 --steps 2 --warmup 1 > /dev/null 2> $O/fetch_c4.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_c4 -o w --output-format csv -- python $R/bench.py --config c4 $B --inflight 1 --steps 2 --warmup 1 > /dev/null 2> $O/write_c4.err || exit 1
 echo "pmc c4 done"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_c2 -o f --output-format csv -- python $R/bench.py --config c2 $B --inflight 1 --steps 4 --warmup 1 > /dev/null 2> $O/fetch_c2.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_c2 -o w --output-format csv -- python $R/bench.py --config c2 $B --inflight 1 --steps 4 --warmup 1 > /dev/null 2> $O/write_c2.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_c2 -o p --output-format csv -- python $R/tools/c2bench.py > $O/c2bench_under_rocprof.txt 2> $O/stats_c2.err || exit 1
+echo "pmc / stats c2 done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_c3 -o s --output-format csv -- python $R/bench.py $B --inflight 1 --steps 3 --warmup 1 > /dev/null 2> $O/sq_c3.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_c4 -o s --output-format csv -- python $R/bench.py --config c4 $B --inflight 1 --steps 2 --warmup 1 > /dev/null 2> $O/sq_c4.err || exit 1
 echo "sq done"
@@ -33,6 +37,15 @@ timeout -k 10 200 python tools/opbench.py all --batch 256 2>&1 | cut -c1-110 | g
 PLHIP_GEMM_WIDE=0 timeout -k 10 200 python tools/opbench.py pw 2>&1 | cut -c1-110 > $O/opbench_pw_wide_off.txt || exit 1
 for l in pw8 pw6 pw13 pw14; do PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/wide_timeline.py $l > $O/wide_timeline_$l.txt 2>&1 || exit 1; done
 PLHIP_GEMM_WIDE=0 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/gemm_timeline.py pw8 > $O/gemm_timeline_pw8_ring.txt 2>&1 || exit 1
+# the patch kernel (conv_patch_i8.hip): config #2 and ResNet50's 3x3 layers, A/B against the ring kernel's implicit GEMM, the
+# in-kernel timelines, the time without the epilogue, and the depthwise 5x5 rows
+timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3.txt || exit 1
+PLHIP_CONV_PATCH=0 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_patch_off.txt || exit 1
+PLHIP_GEMM_DEBUG=1 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_no_epilogue.txt || exit 1
+timeout -k 10 200 python tools/opbench.py all --net dw5x5 2>&1 | cut -c1-110 > $O/opbench_dw5x5.txt || exit 1
+PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py > $O/patch_timeline_c2.txt 2>&1 || exit 1
+ROUNDS=4 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 64 --cout 64 --hw 56 > $O/patch_timeline_res2.txt 2>&1 || exit 1
+PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 256 --cout 256 --hw 14 > $O/patch_timeline_res4.txt 2>&1 || exit 1
 echo "tables done"
 timeout -k 10 400 python bench.py --layer-table > $O/bench.json 2> $O/layer_table.txt || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_inflight1.json 2>/dev/null || exit 1

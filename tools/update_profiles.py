@@ -30,7 +30,8 @@ cp("bench_inflight1.json", "bench_inflight1.json")
 for f in ("bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.json", "layer_table_c4.txt", "layer_table_c5.txt",
           "opbench_b256.txt", "opbench_pw_wide_off.txt", "wide_timeline_pw8.txt", "wide_timeline_pw6.txt", "wide_timeline_pw13.txt",
           "wide_timeline_pw14.txt", "gemm_timeline_pw8_ring.txt", "c2bench.txt", "pmc_sq_c3.csv", "pmc_sq_c4.csv",
-          "bench_driver_form.json"):
+          "bench_driver_form.json", "opbench_resnet50_3x3.txt", "opbench_resnet50_3x3_patch_off.txt", "opbench_resnet50_3x3_no_epilogue.txt",
+          "opbench_dw5x5.txt", "patch_timeline_c2.txt", "patch_timeline_res2.txt", "patch_timeline_res4.txt"):
     if os.path.exists(os.path.join(E, f)):
         cp(f, f)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -47,6 +48,11 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             o.write('"%s",%d,%.1f,%.1f\n' % (k, n, v, v / n))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(E, "fetch"),
                        os.path.join(E, "write"), os.path.join(P, "pmc_traffic.json")], stdout=subprocess.DEVNULL)
+if os.path.isdir(os.path.join(E, "stats_c2")):
+    cp("stats_c2/p_kernel_stats.csv", "kernel_stats_c2bench.csv")
+if os.path.isdir(os.path.join(E, "fetch_c2")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(E, "fetch_c2"),
+                           os.path.join(E, "write_c2"), os.path.join(P, "pmc_traffic_c2.json")], stdout=subprocess.DEVNULL)
 if os.path.isdir(os.path.join(E, "fetch_c4")):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(E, "fetch_c4"),
                            os.path.join(E, "write_c4"), os.path.join(P, "pmc_traffic_c4.json")], stdout=subprocess.DEVNULL)
