@@ -107,7 +107,11 @@ void launch_pack_conv_patch(const int8_t* w_oihw, int8_t* wp, int cin, int cout,
 __global__ __launch_bounds__(256) void pad_rows8_i8_kernel(PadArgs a) {
   const long nq = a.total >> 4;
   const uint32_t plane_sz = (uint32_t)a.ph * (uint32_t)a.pw;
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+  // workgroups are dealt round-robin over the 8 XCDs: block b writes the (b % 8)-th eighth of the buffer, i.e. XCD x the
+  // images whose tiles conv_patch_i8_kernel gives to XCD x (its L2 then holds what that kernel's blocks read first)
+  const long nbx = (gridDim.x + 7) >> 3;
+  const long vb = (long)(blockIdx.x & 7) * nbx + (blockIdx.x >> 3);
+  for (long q = vb * blockDim.x + threadIdx.x; q < nq; q += 8 * nbx * blockDim.x) {
     unsigned long long out[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -158,6 +162,7 @@ void launch_pad_rows8(PadArgs a, hipStream_t s) {  // a.pw % 8 == 0, a.total % 1
   a.div_pw_m = m; a.div_pw_s = sh;
   long blocks = ((a.total >> 4) + 255) / 256;
   if (blocks > 65536) blocks = 65536;
+  blocks = (blocks + 7) & ~7L;  // whole rounds over the 8 XCDs (the kernel's block map)
   hipLaunchKernelGGL(pad_rows8_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
@@ -178,7 +183,9 @@ static inline void magic_u31(long d, unsigned& m, int& sh, bool general_pow2 = f
 void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   static int dbg_env = -1;
   if (dbg_env < 0) {
-    const char* e = getenv("PLHIP_GEMM_DEBUG");
+    // its OWN variable (diagnostics only): 1 = no epilogue (timing experiments), 32 = timeline stamps.  (PLHIP_GEMM_DEBUG
+    // also re-routes the GEMM kernels of the other layers, e.g. 7-wide implicit-GEMM rows onto a kernel that cannot run them.)
+    const char* e = getenv("PLHIP_PATCH_DEBUG");
     dbg_env = e ? atoi(e) : 0;
   }
   a.dbg = dbg_env;
@@ -201,12 +208,12 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   // blocks: 8 XCDs x MB x NQ, each with NH tile streams; the register-resident variants run 4-wave blocks (NH = 1), two per
   // CU: 512 blocks fill the chip, the ring variant one 8-wave block (NH = 2) per CU
   const int NH = stat ? 1 : 2;
-  const int spx = 8 * NH;                                  // streams per unit of NQ
+  a.T8 = (a.T + 7) / 8;                                    // XCD x works through the tiles [x T8, (x + 1) T8)
   const int nq_max = (64 / NH) / a.MB > 0 ? (64 / NH) / a.MB : 1;
-  int nq = (a.T + spx - 1) / spx;
+  int nq = (a.T8 + NH - 1) / NH;
   nq = nq < 1 ? 1 : (nq > nq_max ? nq_max : nq);
-  a.rounds = (a.T + spx * nq - 1) / (spx * nq);
-  nq = (a.T + spx * a.rounds - 1) / (spx * a.rounds);  // the fewest blocks that need no more rounds
+  a.rounds = (a.T8 + NH * nq - 1) / (NH * nq);
+  nq = (a.T8 + NH * a.rounds - 1) / (NH * a.rounds);  // the fewest blocks that need no more rounds
   a.NQ = nq;
   static int delay_env = -1;
   if (delay_env < 0) {

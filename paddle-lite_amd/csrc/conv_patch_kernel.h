@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   static_assert(WMH * WNH == 4 && NSLOT >= 3 && NSLOT <= 4 && (NH == 1 || NH == 2), "layout");
   PLHIP_PRELOAD(a.xp); PLHIP_PRELOAD(a.wp); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias);
   PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.M); PLHIP_PRELOAD(a.OH); PLHIP_PRELOAD(a.OW); PLHIP_PRELOAD(a.PWp); PLHIP_PRELOAD(a.PLANE);
-  PLHIP_PRELOAD(a.NCH); PLHIP_PRELOAD(a.pitch); PLHIP_PRELOAD(a.pps); PLHIP_PRELOAD(a.TPI); PLHIP_PRELOAD(a.T);
+  PLHIP_PRELOAD(a.NCH); PLHIP_PRELOAD(a.pitch); PLHIP_PRELOAD(a.pps); PLHIP_PRELOAD(a.TPI); PLHIP_PRELOAD(a.T); PLHIP_PRELOAD(a.T8);
   PLHIP_PRELOAD(a.MB); PLHIP_PRELOAD(a.NQ); PLHIP_PRELOAD(a.rounds); PLHIP_PRELOAD(a.HWY); PLHIP_PRELOAD(a.y_bstride);
   PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha); PLHIP_PRELOAD(a.pw_m); PLHIP_PRELOAD(a.pw_s); PLHIP_PRELOAD(a.tpi_m);
   PLHIP_PRELOAD(a.tpi_s); PLHIP_PRELOAD(a.pitch_m); PLHIP_PRELOAD(a.pitch_s); PLHIP_PRELOAD(a.dbg); PLHIP_PRELOAD(a.res);
@@ -67,9 +67,16 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   // ---- block -> (XCD, M block, n-block slot); stream of a half = 2 nq + half inside the XCD's contiguous tile range
   const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
   const int mb = bq % a.MB, nq = bq / a.MB;
-  const int S = 8 * NH * a.NQ;                         // tile streams in all
-  const int sig0 = (bx * a.NQ + nq) * NH;              // stream of half 0 (half 1: + 1)
-  const int sig = sig0 + half;
+  // XCD x owns the CONTIGUOUS tiles [x T8, (x + 1) T8) for the whole kernel (its images' padded copy was written by the same
+  // XCD, pad_rows8_i8_kernel: the reads hit the local L2 instead of crossing the fabric; neighbouring tiles share their halo
+  // rows there too).  Inside it: stream li of SX = NQ NH takes the tiles x T8 + k SX + li, k = 0, 1, ..
+  const int SX = a.NQ * NH, li0 = nq * NH;
+  auto tile_of = [&](int k, int li, bool& live) __attribute__((always_inline)) -> int {
+    const int j = k * SX + li;
+    const int t = bx * a.T8 + j;
+    live = j < a.T8 && t < a.T;
+    return live ? t : a.T - 1;  // idle streams re-read the last tile (every step issues the same number of DMA pieces)
+  };
   const int MT32 = (a.M + 31) >> 5;
   const int mt = mb * WMH + wm;                        // my 32-row m tile
   const int mtc = mt < MT32 ? mt : MT32 - 1;           // tiles past M: any packed tile (their rows are never stored)
@@ -148,8 +155,8 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     ik = ik < a.rounds ? ik : a.rounds - 1;  // past the end: a harmless re-fetch (keeps the per-step issue count constant)
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
-      int t = ik * S + sig0 + hf;
-      t = t < a.T ? t : a.T - 1;
+      bool lv;
+      const int t = tile_of(ik, li0 + hf, lv);
       const uint32_t b = fastdiv_u31((uint32_t)t, a.tpi_m, a.tpi_s);
       const int p0 = (t - (int)b * a.TPI) * NTH;
       cb[hf] = reinterpret_cast<const uint8_t*>(a.xp) + (size_t)b * a.C * (uint32_t)a.PLANE + p0;
@@ -494,9 +501,8 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   using std::integral_constant;
   int nstamp = 22;  // 5-10: barrier of step i passed, 11-16: its MFMAs issued, 18-21: first epilogue, 22..: end of round k
   for (int k = 0; k < a.rounds; ++k) {
-    const int t = k * S + sig;
-    const bool live = t < a.T;                                     // wave-uniform
-    const int tc = live ? t : a.T - 1;
+    bool live;                                                     // wave-uniform
+    const int tc = tile_of(k, li0 + half, live);
     const int b = (int)fastdiv_u31((uint32_t)tc, a.tpi_m, a.tpi_s);
     const int p0 = (tc - b * a.TPI) * NTH;
     if constexpr (STAT) {
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         step(IR{}, integral_constant<int, 2>{}, integral_constant<int, 0>{}, false, false);
       }
     }
-    if (live && !(a.dbg & 1)) {  // (PLHIP_GEMM_DEBUG & 1: no epilogue; timing experiments)
+    if (live && !(a.dbg & 1)) {  // (PLHIP_PATCH_DEBUG & 1: no epilogue; timing experiments)
       // (opaque copies: the address arithmetic of the epilogue must not be hoisted above the K loop, where its lane masks
       // and offsets would sit in registers for the whole tile)
       int be = b, pe = p0, me = mt;

@@ -1001,7 +1001,10 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
     if (t.XP > 0 && t.XP < t.HWX) t.HWX = t.XP;  // the TRUE row length of a dense slab
     if (launch_gemm_wide(t, out, s)) return;
   }
-  if (g.M > 32 && (g.im_kw > 0 || (gemm_variant() == 0 && gemm_tr_enabled() >= 2)) && (dbg_env & ~96) == 0) {
+  // (stride-2 / short-row implicit GEMMs exist on the transposed-read kernel ONLY: the timing bits of PLHIP_GEMM_DEBUG must
+  // not send them to a first-generation kernel, which would read outside its operands: a GPU memory fault, seen once)
+  const bool tr_only = g.im_kw > 0 && (g.im_s == 2 || g.HWX < 16);
+  if (g.M > 32 && (g.im_kw > 0 || (gemm_variant() == 0 && gemm_tr_enabled() >= 2)) && ((dbg_env & ~96) == 0 || tr_only)) {
     GemmArgs t = g;
     if (t.im_kw == 0 && t.XP > 0 && t.XP < t.HWX) t.HWX = t.XP;
     if (launch_gemm_tr(t, out, s)) return;

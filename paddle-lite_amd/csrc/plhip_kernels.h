@@ -70,7 +70,7 @@ struct PatchArgs {
   int PWp, PLANE;      // row pitch (multiple of 8) and plane size PH * PWp of the padded copy
   int NCH;             // 32-channel chunks: C / 32
   int pitch, pps;      // LDS bytes per channel row of a slab (odd multiple of 32, >= tile + 2 PWp), pitch / 32
-  int TPI, T;          // tiles per image, tiles in all
+  int TPI, T, T8;      // tiles per image, tiles in all, tiles per XCD (ceil(T / 8))
   int MB, NQ, rounds;  // M blocks, blocks per XCD and M block, tiles per stream
   int HWY;             // OH * OW
   size_t y_bstride;    // M * OH * OW

@@ -41,11 +41,11 @@ PLHIP_GEMM_WIDE=0 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/gemm_timeli
 # in-kernel timelines, the time without the epilogue, and the depthwise 5x5 rows
 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3.txt || exit 1
 PLHIP_CONV_PATCH=0 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_patch_off.txt || exit 1
-PLHIP_GEMM_DEBUG=1 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_no_epilogue.txt || exit 1
+PLHIP_PATCH_DEBUG=1 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_no_epilogue.txt || exit 1
 timeout -k 10 200 python tools/opbench.py all --net dw5x5 2>&1 | cut -c1-110 > $O/opbench_dw5x5.txt || exit 1
-PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py > $O/patch_timeline_c2.txt 2>&1 || exit 1
-ROUNDS=4 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 64 --cout 64 --hw 56 > $O/patch_timeline_res2.txt 2>&1 || exit 1
-PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 256 --cout 256 --hw 14 > $O/patch_timeline_res4.txt 2>&1 || exit 1
+PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py > $O/patch_timeline_c2.txt 2>&1 || exit 1
+ROUNDS=4 PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 64 --cout 64 --hw 56 > $O/patch_timeline_res2.txt 2>&1 || exit 1
+PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 256 --cout 256 --hw 14 > $O/patch_timeline_res4.txt 2>&1 || exit 1
 echo "tables done"
 timeout -k 10 400 python bench.py --layer-table > $O/bench.json 2> $O/layer_table.txt || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_inflight1.json 2>/dev/null || exit 1

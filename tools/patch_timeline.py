@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Timeline of one patch-kernel launch (conv_patch_i8.hip) from in-kernel s_memtime stamps (PLHIP_GEMM_DEBUG=32).
-Usage: PLHIP_GEMM_DEBUG=32 python tools/patch_timeline.py [--n 32 --cin 64 --cout 128 --hw 56]"""
+"""Timeline of one patch-kernel launch (conv_patch_i8.hip) from in-kernel s_memtime stamps (PLHIP_PATCH_DEBUG=32).
+Usage: PLHIP_PATCH_DEBUG=32 python tools/patch_timeline.py [--n 32 --cin 64 --cout 128 --hw 56]"""
 import argparse
 import ctypes as C
 import os
@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--cout", type=int, default=128)
     ap.add_argument("--hw", type=int, default=56)
     a = ap.parse_args()
-    assert int(os.environ.get("PLHIP_GEMM_DEBUG", "0")) & 32, "run with PLHIP_GEMM_DEBUG=32"
+    assert int(os.environ.get("PLHIP_PATCH_DEBUG", "0")) & 32, "run with PLHIP_PATCH_DEBUG=32"
     rng = np.random.default_rng(0)
     n, cin, cout, hw = a.n, a.cin, a.cout, a.hw
     with capi.Context(0) as ctx:
