@@ -1128,9 +1128,76 @@ void launch_pad_input(const PadArgs& a_in, hipStream_t s) {
   hipLaunchKernelGGL(pad_input_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
+// 1x1 stride-2 convs (ResNet50's downsampling shortcuts: lite/backends/arm/math/conv_impl.cc:490-598 runs them through
+// im2col too): the "im2col" is a strided gather, col[b][c][oy * ow + ox] = x[b][c][2 oy][2 ox].  One thread = 16 output
+// bytes = 4 quads, each ONE unaligned 8-byte fetch with every other byte kept, one 16-byte store (the dword-per-thread
+// form above ran the three shortcut copies of a ResNet50 step at 2.3 TB/s, 0.33 ms per 256 images: 4-byte stores).
+// Needs kh = kw = 1, no padding in use, sw = 2.
+__global__ __launch_bounds__(256) void subsample2_1x1_i8_kernel(Im2colArgs a) {
+  // flat index -> (row = (image, group, channel), 16-byte chunk): a (chunks, channels, images) grid of mostly empty 256-thread
+  // blocks (49 chunks per 28x28 row) was bound by the workgroup dispatch rate: 65 k blocks for 51 MB
+  const int nch = (a.Np + 15) >> 4;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.rows * (size_t)nch) return;
+  const uint32_t rowi = (uint32_t)(idx / (uint32_t)nch);
+  const int q16 = (int)(idx - (size_t)rowi * nch);
+  const int bg = (int)(rowi / (uint32_t)a.Kg), k = (int)(rowi - (uint32_t)bg * a.Kg);
+  const int b = bg / a.G, grp = bg - b * a.G;
+  const int8_t* xp = a.x + ((size_t)b * a.cin + (size_t)grp * a.cin_g + k) * a.h * a.w;
+  const size_t row = (size_t)bg * a.Kg + k;
+  const int n0 = q16 * 16;
+  int oy = (int)((uint32_t)n0 / (uint32_t)a.ow), ox = n0 - oy * a.ow;
+  uint32_t out[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int n = n0 + 4 * d;
+    if (n + 3 < a.N && ox + 3 < a.ow && ox * 2 + 7 < a.w) {  // the quad inside one output row, its 8 source bytes inside the input row
+      uint32_t dd[2];
+      __builtin_memcpy(dd, xp + (size_t)(oy * a.sh) * a.w + ox * 2, 8);
+      out[d] = __builtin_amdgcn_perm(dd[1], dd[0], 0x06040200u);
+      ox += 4;
+      if (ox >= a.ow) {
+        ox -= a.ow;
+        ++oy;
+      }
+    } else {  // a quad across two output rows (14- and 7-wide planes), the row's last quad when w is odd, the plane's tail
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (n + i < a.N) out[d] |= (uint32_t)(uint8_t)xp[(size_t)(oy * a.sh) * a.w + ox * 2] << (8 * i);
+        if (++ox == a.ow) {
+          ox = 0;
+          ++oy;
+        }
+      }
+    }
+  }
+  int8_t* dst = a.col + row * a.Np + (size_t)n0;
+  if (n0 + 16 <= a.Np) {
+    const v4i v = {(int)out[0], (int)out[1], (int)out[2], (int)out[3]};
+    __builtin_memcpy(dst, &v, 16);  // (rows are 4-byte aligned: Np % 4 == 0)
+  } else {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      if (n0 + 4 * d < a.Np) __builtin_memcpy(dst + 4 * d, &out[d], 4);
+  }
+}
+
 void launch_im2col(const Im2colArgs& a, hipStream_t s) {
   // rows = batch * G * Kg; Kg and batch*G ride on grid.y / grid.z (<= 65535 each, checked by the caller)
   const unsigned bg = (unsigned)(a.rows / (size_t)a.Kg);
+  static int sub_env = -1;
+  if (sub_env < 0) {
+    const char* e = getenv("PLHIP_SUBSAMPLE_1X1");  // 0 = the generic im2col kernel (A/B runs)
+    sub_env = e ? atoi(e) : 1;
+  }
+  if (sub_env && a.kh == 1 && a.kw == 1 && a.pt == 0 && a.pl == 0 && a.sw == 2 && a.Kg == a.cin_g &&
+      (a.oh - 1) * a.sh < a.h && (a.ow - 1) * 2 < a.w) {  // (no tap in a bottom / right padding)
+    const size_t threads = a.rows * (size_t)((a.Np + 15) >> 4);
+    if (threads < ((size_t)1 << 31) * 256) {
+      hipLaunchKernelGGL(subsample2_1x1_i8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+      return;
+    }
+  }
   hipLaunchKernelGGL(im2col_i8_kernel, dim3((unsigned)(((a.Np >> 2) + 255) / 256), (unsigned)a.Kg, bg), dim3(256), 0, s, a);
 }
 

@@ -320,6 +320,20 @@ def test_implicit_gemm_route(gpu_ctx, pkg, plref):
                                 act != 4, rng) == 1
 
 
+def test_conv1x1_stride2_subsample(gpu_ctx, pkg, plref):
+    """1x1 stride-2 convs (ResNet50's shortcuts) gather their GEMM operand with subsample2_1x1_i8_kernel (16 bytes per thread)
+    : even and odd input extents (the row's last quad), output planes that are not a multiple of 16 columns, quads across two
+    output rows (OW = 14, 7, 4, 12), groups, bottom / right padding (falls back to the generic im2col kernel)."""
+    rng = np.random.default_rng(133)
+    capi = pkg.capi
+    cases = [  # n, cin, h, w, cout, pads, groups, act
+        (2, 64, 56, 56, 128, (0, 0, 0, 0), 1, 0), (3, 48, 15, 23, 40, (0, 0, 0, 0), 1, 1), (2, 32, 9, 8, 64, (0, 0, 0, 0), 2, 2),
+        (1, 256, 28, 28, 96, (0, 0, 0, 0), 1, 1), (2, 24, 8, 8, 33, (0, 1, 0, 1), 1, 0), (2, 40, 13, 13, 50, (0, 0, 0, 0), 1, 4),
+        (2, 96, 14, 14, 64, (0, 0, 0, 0), 1, 1), (3, 64, 28, 27, 48, (0, 0, 0, 0), 1, 0)]
+    for (n, cin, h, w, cout, pads, g, act) in cases:
+        assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 1, 1, pads, 2, 1, g, act, 6.0 if act == 2 else 0.25, True, rng) == 1
+
+
 def test_patch_conv_route(gpu_ctx, pkg, plref):
     """Dense 3x3 stride-1 convs with Cin % 32 == 0 on the patch kernel (conv_patch_i8.hip): register-resident weights
     (Cin = 64) in both wave layouts (M > 64: 4 m tiles x 1 pixel group per half, M <= 64: 2 x 2), weights through the ring
