@@ -1,4 +1,5 @@
 // lite_capi.cc — see lite_capi.h.
+#include "lite/kernels/hip/packed_weight_cache.h"
 #include "lite/api/lite_capi.h"
 
 #include <cstring>
@@ -41,6 +42,13 @@ int pllite_registered_kernels(const char* op_type, int precision, int layout) {
                                                          static_cast<paddle::lite::PrecisionType>(precision),
                                                          static_cast<paddle::lite::DataLayoutType>(layout));
   return static_cast<int>(ks.size());
+}
+
+// how often a kernel object found its packed weights already on the device / packed them itself (packed_weight_cache.h)
+void pllite_packed_weight_cache_stats(long* hits, long* misses) {
+  auto& c = paddle::lite::kernels::hip::PackedWeightCache::Global();
+  if (hits) *hits = c.hits();
+  if (misses) *misses = c.misses();
 }
 
 int pllite_adopt_stream(int device, void* stream) {

@@ -5,6 +5,7 @@
 // registrations of conv_compute.cc:216-252.  Differences by design: 3x3s1 goes through the
 // direct accumulator (im2col GEMM), not the integer Winograd transform, and 3x3s2 needs no special DirectConv.
 #include "lite/kernels/hip/conv_compute.h"
+#include "lite/kernels/hip/packed_weight_cache.h"
 
 #include "lite/core/op_registry.h"
 
@@ -185,22 +186,35 @@ void ConvCompute<Ptype, OutType>::PrepareForRun() {
   desc_.act_alpha = act_alpha_;
 
   // ---- weights: pre-pack once (trans_gemm_weights<kInt8> -> prepackA_int8 analogue), or keep OIHW for depthwise
-  Tensor staged;
+  // One packed device copy per process and device (packed_weight_cache.h): predictors that run the same model — the three
+  // in flight of bench.py, a serving process with a predictor per thread (cxx_api.h:103-137) — share it; host-resident
+  // weights are the key (persistable params of a model; weights already on the device are packed privately).
   const size_t w_bytes = static_cast<size_t>(param.filter->numel());
-  const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(param.filter, &staged, w_bytes));
-  if (is_depthwise_) {
-    void* d = weights_.mutable_data(TARGET(kHIP), w_bytes);
-    ctx.MemcpySync(d, w_dev, w_bytes, IoDirection::DtoD);
-    kernel_func_name_ = std::string("conv_depthwise_") + std::to_string(desc_.kh) + "x" + std::to_string(desc_.kw) +
-                        (kInt8Out ? "_int8_int8_hip" : "_int8_fp32_hip");
+  const size_t packed = is_depthwise_ ? w_bytes : plhip_conv_packed_weight_bytes(&desc_);
+  CHECK_GT(packed, 0UL) << "invalid conv configuration";
+  auto pack_into = [&](void* d) {
+    Tensor staged;
+    const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(param.filter, &staged, w_bytes));
+    if (is_depthwise_) {
+      ctx.MemcpySync(d, w_dev, w_bytes, IoDirection::DtoD);
+    } else {
+      HIP_CALL(ctx.ctx(), plhip_pack_conv_weights(ctx.ctx(), &desc_, w_dev, d));
+    }
+    ctx.Sync();  // the bytes are final (and `staged` may die) before anybody else sees them
+  };
+  if (param.filter->target() == TARGET(kHost)) {
+    const auto wd = param.filter->dims();
+    std::string layout = is_depthwise_ ? std::string("dw_oihw") : std::string(plhip_conv_impl_name(&desc_));
+    for (size_t i = 0; i < wd.size(); ++i) layout += "_" + std::to_string(wd[i]);
+    layout += "_g" + std::to_string(desc_.groups) + "_w" + std::to_string(desc_.w) + "_p" + std::to_string(desc_.pad[2]) + "_" + std::to_string(desc_.pad[3]);
+    packed_owner_ = PackedWeightCache::Global().GetOrPack(static_cast<int>(TargetWrapperHip::GetCurDevice()), layout, param.filter->raw_data(), w_bytes, packed, pack_into);
+    weights_.ShareDataWith(*packed_owner_);
   } else {
-    const size_t packed = plhip_conv_packed_weight_bytes(&desc_);
-    CHECK_GT(packed, 0UL) << "invalid conv configuration";
-    void* d = weights_.mutable_data(TARGET(kHIP), packed);
-    HIP_CALL(ctx.ctx(), plhip_pack_conv_weights(ctx.ctx(), &desc_, w_dev, d));
-    ctx.Sync();  // `staged` dies at scope exit
-    kernel_func_name_ = plhip_conv_impl_name(&desc_);
+    pack_into(weights_.mutable_data(TARGET(kHIP), packed));
   }
+  kernel_func_name_ = is_depthwise_ ? std::string("conv_depthwise_") + std::to_string(desc_.kh) + "x" + std::to_string(desc_.kw) +
+                                          (kInt8Out ? "_int8_int8_hip" : "_int8_fp32_hip")
+                                    : std::string(plhip_conv_impl_name(&desc_));
   if (fusion_.pw_filter) PreparePointwise();
   last_shape_ = DDim();
   ReInitWhenNeeded();

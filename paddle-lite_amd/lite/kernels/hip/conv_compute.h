@@ -2,6 +2,7 @@
 // lite/kernels/arm/conv_compute.h:27-58 (+ conv_gemmlike / conv_depthwise / conv_direct / conv_winograd,
 // which collapse into two device paths here: MFMA GEMM and depthwise).
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,7 @@ class ConvCompute : public KernelLite<TARGET(kHIP), Ptype>, public HipFusableKer
   bool is_depthwise_{false};
   DDim last_shape_;
   Tensor weights_;   // packed (GEMM path) or raw OIHW (depthwise path), on device
+  std::shared_ptr<Tensor> packed_owner_;  // the process-wide shared copy weights_ aliases (packed_weight_cache.h), if any
   Tensor scale_;     // folded per-channel scale, device
   Tensor bias_;      // folded bias, device (only if param.bias)
   bool has_bias_{false};

@@ -4,6 +4,7 @@
 //   int8-out bias_j = bias[j] / out (read from param.bias — the reference reads its own uninitialised buffer,
 //   fc_compute.cc:154-163, which is a bug and is not reproduced); activation_type == "relu" only.
 // One device kernel serves every m (no gemv/gemm split) with a per-column scale.
+#include "lite/kernels/hip/packed_weight_cache.h"
 #include <string>
 #include <vector>
 
@@ -63,17 +64,28 @@ class FcCompute : public KernelLite<TARGET(kHIP), Ptype> {
       TargetWrapperHip::MemcpySync(bias_.mutable_data<float>(TARGET(kHIP)), b.data(), n_ * sizeof(float), IoDirection::HtoD);
     }
     // weight pre-pack [k,n] -> [k/4][n][4] (replaces the transpose of fc_compute.cc:53-62)
-    Tensor staged;
+    // (one packed device copy per process and device, shared by the predictors that run the same model: packed_weight_cache.h)
     const size_t wb = static_cast<size_t>(k_) * n_;
-    const void* w_dev = param.w->raw_data();
-    if (param.w->target() != TARGET(kHIP)) {
-      void* d = staged.mutable_data(TARGET(kHIP), wb);
-      TargetWrapperHip::MemcpySync(d, param.w->raw_data(), wb, IoDirection::HtoD);
-      w_dev = d;
+    auto pack_into = [&](void* wp) {
+      Tensor staged;
+      const void* w_dev = param.w->raw_data();
+      if (param.w->target() != TARGET(kHIP)) {
+        void* d = staged.mutable_data(TARGET(kHIP), wb);
+        TargetWrapperHip::MemcpySync(d, param.w->raw_data(), wb, IoDirection::HtoD);
+        w_dev = d;
+      }
+      HIP_CALL(ctx.ctx(), plhip_pack_fc_weights(ctx.ctx(), k_, n_, static_cast<const int8_t*>(w_dev), wp));
+      ctx.Sync();
+    };
+    const size_t packed = plhip_fc_packed_weight_bytes(k_, n_);
+    if (param.w->target() == TARGET(kHost)) {
+      packed_owner_ = PackedWeightCache::Global().GetOrPack(static_cast<int>(TargetWrapperHip::GetCurDevice()),
+                                                            "fc_" + std::to_string(k_) + "_" + std::to_string(n_), param.w->raw_data(), wb,
+                                                            packed, pack_into);
+      weights_.ShareDataWith(*packed_owner_);
+    } else {
+      pack_into(weights_.mutable_data(TARGET(kHIP), packed));
     }
-    void* wp = weights_.mutable_data(TARGET(kHIP), plhip_fc_packed_weight_bytes(k_, n_));
-    HIP_CALL(ctx.ctx(), plhip_pack_fc_weights(ctx.ctx(), k_, n_, static_cast<const int8_t*>(w_dev), wp));
-    ctx.Sync();
   }
 
   void Run() override {
@@ -104,6 +116,7 @@ class FcCompute : public KernelLite<TARGET(kHIP), Ptype> {
   int m_{0}, k_{0}, n_{0};
   bool relu_{false}, has_bias_{false}, single_scale_{false};
   Tensor weights_, scale_, bias_;
+  std::shared_ptr<Tensor> packed_owner_;  // the shared copy weights_ aliases, if any
 };
 
 }  // namespace hip

@@ -29,6 +29,8 @@ def load():
     L.pllite_last_error.restype = cs
     L.pllite_registered_kernels.argtypes = [cs, i32, i32]
     L.pllite_adopt_stream.argtypes = [i32, vp]
+    L.pllite_packed_weight_cache_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.pllite_packed_weight_cache_stats.restype = None
     L.pllite_predictor_create.argtypes = [i32]
     L.pllite_predictor_create.restype = vp
     L.pllite_predictor_destroy.argtypes = [vp]

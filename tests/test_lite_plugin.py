@@ -226,6 +226,56 @@ def test_concurrent_predictors_reproduce_the_serial_result(lite, wl, plref):
 
 
 @pytest.mark.gpu
+def test_predictors_of_one_model_share_the_packed_weights(lite, wl):
+    """The serving shape of lite/api/cxx_api.h:103-137 (a predictor per thread, Clone() sharing the persistable variables):
+    here the pre-packed DEVICE copy a conv / fc kernel object owns is shared per process and device, keyed on the weight
+    bytes and the packing (packed_weight_cache.h).  A second predictor of the same model packs nothing, computes the same
+    bytes, and the copies die with the last predictor that uses them."""
+    import ctypes as C
+    L = lite.load()
+
+    def stats():
+        h, m = C.c_long(), C.c_long()
+        L.pllite_packed_weight_cache_stats(C.byref(h), C.byref(m))
+        return h.value, m.value
+
+    B = 2
+    W = wl.make_mobilenet_v1_weights(seed=77)
+    img = np.random.default_rng(203).uniform(-1, 1, (B, 3, 224, 224)).astype(np.float32)
+    h0, m0 = stats()
+    p1 = lite.Predictor(0)
+    p2 = lite.Predictor(0)
+    try:
+        o1 = wl.build_mobilenet_v1(p1, W, B)
+        p1.set_input("image", img)
+        p1.run()
+        p1.sync()
+        h1, m1 = stats()
+        assert m1 - m0 == 28 and h1 == h0, (h0, m0, h1, m1)  # 27 convs + fc packed once
+        o2 = wl.build_mobilenet_v1(p2, W, B)
+        p2.set_input("image", img)
+        p2.run()
+        p2.sync()
+        h2, m2 = stats()
+        assert m2 == m1 and h2 - h1 == 28, (h1, m1, h2, m2)  # the second predictor found all of them
+        assert np.array_equal(p1.get_var(o1, np.float32), p2.get_var(o2, np.float32))
+        assert np.array_equal(p1.get_var("pw8", np.int8), p2.get_var("pw8", np.int8))
+    finally:
+        p1.close()
+        p2.close()
+    p3 = lite.Predictor(0)
+    try:
+        wl.build_mobilenet_v1(p3, W, B)
+        p3.set_input("image", img)
+        p3.run()
+        p3.sync()
+        h3, m3 = stats()
+        assert m3 - m2 == 28, (m2, m3)  # the shared copies died with p1 / p2: packed again
+    finally:
+        p3.close()
+
+
+@pytest.mark.gpu
 def test_predictor_keeps_its_stream_across_threads(lite, plref):
     """The execution state (stream + workspace) belongs to the predictor, not to the calling thread: built on one
     thread, run on another, read back on a third — same bytes (lite/backends/cuda/context.h keeps the stream in the
