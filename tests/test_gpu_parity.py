@@ -388,6 +388,31 @@ def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
     np.testing.assert_allclose(gpu_ctx.softmax(xs), plref.softmax(xs), rtol=1e-5, atol=1e-7)
 
 
+def test_patch_conv_random_shapes(gpu_ctx, pkg, plref):
+    """Random sweep over the patch kernel's shape space (the reference's random grid, conv_int8_compute_test.cc:676-731, narrowed
+    to 3x3 stride 1 with whole 32-channel chunks): batch 1-9, Cin 64-192, 6-60 rows / columns (row pitches 16-64 incl. the
+    shared pad column), Cout 32-300 (M tails, M blocks), pads 0-2 per side, every activation, bias on / off."""
+    rng = np.random.default_rng(135)
+    capi = pkg.capi
+    done = 0
+    for _ in range(60):
+        cin = int(rng.choice([64, 96, 128, 160, 192]))
+        cout = int(rng.integers(32, 301))
+        if cout <= 64 and cin != 64:
+            cout += 64
+        n, h, w = int(rng.integers(1, 10)), int(rng.integers(6, 61)), int(rng.integers(6, 61))
+        pads = tuple(int(v) for v in rng.integers(0, 3, 4))
+        act = int(rng.choice([0, 1, 2, 4]))
+        d = capi.conv_desc(n, cin, h, w, cout, 3, 3, pads, (1, 1), (1, 1), 1, act, 0.0)
+        if gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) != b"conv_patch_gemm_int8_mfma32x32x32":
+            continue  # (row pitch outside 16..64)
+        if n * cout * h * w * cin > 6e9 / 9:
+            continue  # keep the scalar oracle in seconds
+        done += _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 3, 3, pads, 1, 1, 1, act, 6.0 if act == 2 else 0.25,
+                                 bool(rng.integers(0, 2)), rng)
+    assert done >= 20, done
+
+
 def test_full_size_properties_c2(gpu_ctx, pkg, plref):
     """BASELINE config #2 at full size (N=32, 64->128, 56x56, k3 s1 p1): too big for the scalar oracle in
     seconds, so check size-independent properties: (i) linearity in the weights acc(w1+w2) = acc(w1)+acc(w2);
