@@ -98,6 +98,11 @@ int gemm_wide_ntt(const GemmArgs& g) {
 }
 
 bool launch_gemm_wide(const GemmArgs& g_in, int out, hipStream_t s) {
+  // 32-bit outputs: the ring kernels are faster on every MobileNetV1 layer (fp32 out, batch 256: 699 vs 764 us over the 13
+  // layers, 128 -> 256 @28x28 38.7 vs 54.0 us, 1024 -> 1024 @7x7 30.2 vs 37.6: profiles/r03_final_opbench_f32_*.txt): this
+  // kernel's row-per-lane 16-byte stores write 32 contiguous bytes per row and instruction, the ring kernels' epilogue 64.
+  // It stays reachable for them through the tile override (tests, A/B runs).
+  if (out != OUT_I8 && g_wide_ntt_override < 0 && !getenv("PLHIP_WIDE_NTT")) return false;
   const int ntt = gemm_wide_ntt(g_in);
   if (!ntt) return false;
   GemmArgs g = g_in;
