@@ -1013,7 +1013,8 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
   // 64-row tiles whose last tile is at most half full (M = 144: 192 rows computed and stored-checked for 144), and the
   // streaming shapes with K <= 64 and M > 64 (MobileNetV2's expand convs: 24 -> 144 ran at 3.0 TB/s with 64-row tiles,
   // 3.9 with 32-row ones; 64 -> 384 @14x14 12.1 -> 9.8 us): 32-row wave tiles
-  if (ma == 2 && ma_env == 0 && g.im_kw == 0 && (((g.M & 63) != 0 && (g.M & 63) <= 32) || (g.KS <= 2 && g.M > 64))) ma = 1;
+  // (K = 32, M = 64 — MobileNetV1's first pointwise conv — too: 28.7 -> 27.4 us at batch 128)
+  if (ma == 2 && ma_env == 0 && g.im_kw == 0 && (((g.M & 63) != 0 && (g.M & 63) <= 32) || (g.KS <= 2 && g.M > 64) || (g.KS == 1 && g.M == 64))) ma = 1;
   g.MT = (g.M + 32 * ma - 1) / (32 * ma);
   if (ma == 1) {
     if (out == OUT_I32) launch_gemm_t<1, OUT_I32>(g, vec_store, aligned_loads, s);
