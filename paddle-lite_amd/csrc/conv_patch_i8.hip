@@ -68,10 +68,13 @@ bool conv_patch_supported(int cin, int cout, int kh, int kw, int sh, int sw, int
   if (kh != 3 || kw != 3 || sh != 1 || sw != 1 || dh != 1 || dw != 1 || groups != 1) return false;
   if (cin % 32 != 0 || cin < 64 || cout < 32) return false;
   const int pwp = conv_patch_row_pitch(w, pl, pr);
-  if (pwp > 64 || pwp < 16) return false;   // (7-wide planes: PWp = 8 would need multi-image tiles; the ring kernel keeps them)
+  if (pwp > 64 || pwp < 8) return false;
   if (cout <= 64 && cin != 64) return false;  // the 2 x 2 wave layout exists for the register-resident weights only
   return true;
 }
+
+// planes smaller than a tile (7-wide: 72 padded pixels): global mode, the padded copy is channel-major
+bool conv_patch_global(int pwp) { return pwp < 16; }
 
 size_t conv_patch_packed_bytes(int cin, int cout) { return (size_t)((cout + 31) / 32) * (cin / 32) * 9 * 1024; }
 
@@ -116,8 +119,12 @@ __global__ __launch_bounds__(256) void pad_rows8_i8_kernel(PadArgs a) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const uint32_t o = ((uint32_t)q << 4) + 8u * e;
-      const uint32_t plane = fastdiv_u31(o, a.div_plane_m, a.div_plane_s);
+      uint32_t plane = fastdiv_u31(o, a.div_plane_m, a.div_plane_s);
       const uint32_t rem = o - plane * plane_sz;
+      if (a.tb > 0 && (int)plane < a.planes) {  // channel-major copy: output plane (c, b) <- input plane (b, c)
+        const uint32_t c_ = plane / (uint32_t)a.tb, b_ = plane - c_ * (uint32_t)a.tb;
+        plane = b_ * (uint32_t)a.tc + c_;
+      }
       const int ph = (int)fastdiv_u31(rem, a.div_pw_m, a.div_pw_s), pc = (int)rem - ph * a.pw;
       const int ih = ph - a.pt, iw0 = pc - a.pl;
       unsigned long long v = 0;
@@ -197,9 +204,21 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   const bool layout_b = a.M <= 64;                // 2 m tiles x 2 pixel groups per half (else 4 x 1)
   const int NTH = (layout_b ? 2 : 1) * PATCH_NTW * 32;
   const int WMH = layout_b ? 2 : 4;
-  const long P = (long)a.OH * a.PWp;
-  a.TPI = (int)((P + NTH - 1) / NTH);
+  a.glob = conv_patch_global(a.PWp) ? 1 : 0;
+  a.IMGP = a.PLANE;
+  a.nimg = a.B;
+  if (a.glob) {  // p runs over all images of a channel: one "image" of B * IMGP pixels, PLANE = the channel stride
+    const long PT = (long)a.B * a.IMGP;
+    a.PLANE = (int)PT;
+    a.B = 1;
+    a.TPI = (int)((PT + NTH - 1) / NTH);
+  } else {
+    const long P = (long)a.OH * a.PWp;
+    a.TPI = (int)((P + NTH - 1) / NTH);
+  }
   a.T = a.B * a.TPI;
+  magic_u31(a.IMGP, a.imgp_m, a.imgp_s, true);
+  magic_u31(a.HWY > 1 ? a.HWY : 2, a.hwy_m, a.hwy_s, true);
   int pitch = (NTH + 2 * a.PWp + 31) & ~31;
   if (((pitch >> 5) & 1) == 0) pitch += 32;
   a.pitch = pitch;

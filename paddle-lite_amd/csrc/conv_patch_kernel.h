@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   PLHIP_PRELOAD(a.MB); PLHIP_PRELOAD(a.NQ); PLHIP_PRELOAD(a.rounds); PLHIP_PRELOAD(a.HWY); PLHIP_PRELOAD(a.y_bstride);
   PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha); PLHIP_PRELOAD(a.pw_m); PLHIP_PRELOAD(a.pw_s); PLHIP_PRELOAD(a.tpi_m);
   PLHIP_PRELOAD(a.tpi_s); PLHIP_PRELOAD(a.pitch_m); PLHIP_PRELOAD(a.pitch_s); PLHIP_PRELOAD(a.dbg); PLHIP_PRELOAD(a.res);
+  PLHIP_PRELOAD(a.glob); PLHIP_PRELOAD(a.nimg); PLHIP_PRELOAD(a.IMGP); PLHIP_PRELOAD(a.imgp_m); PLHIP_PRELOAD(a.imgp_s); PLHIP_PRELOAD(a.hwy_m); PLHIP_PRELOAD(a.hwy_s);
   PLHIP_PRELOAD(a.y2); PLHIP_PRELOAD(a.inv_scale2); PLHIP_PRELOAD(a.res_relu); PLHIP_PRELOAD(a.stamps); PLHIP_PRELOAD(a.delay);
   extern __shared__ __attribute__((aligned(16))) uint8_t ring[];        // NSLOT x [half 0: 32 x pitch][half 1][weights]
   __shared__ __attribute__((aligned(16))) uint8_t stg_all[NW * 32 * PATCH_SP];  // int8 epilogue staging, one image per wave
@@ -211,7 +212,18 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   // destination offset (inside a channel plane) of p-space pixel p: rows are OW of PWp wide; p past the image -> its end.
   // Branch free (it runs on the scalar unit for wave-uniform p: a branch there is a pipeline bubble per piece): PWp >= 16,
   // so the host's magic is never the power-of-two marker 0 (launch_conv_patch uses the general form for powers of two too)
+  // Global mode (a.glob: 7-wide planes, whose 56..72 pixels are less than a tile): the padded copy is CHANNEL-major
+  // ([c][image][PH][PWp]), so for one channel the images follow each other and p runs over all of them, IMGP pixels each;
+  // the value returned is then a VIRTUAL compact index img * HWY + oh * OW + ow (still monotone in p); virt_to_y maps it
+  // to the output element (images are M * HWY apart for one channel).
   auto dst_of = [&](uint32_t p, int& valid, int span) __attribute__((always_inline)) -> int {
+    int vbase = 0, img_ok = -1;
+    if (a.glob) {  // kernel-uniform
+      const uint32_t img = __umulhi(p, a.imgp_m) >> a.imgp_s;
+      p -= img * (uint32_t)a.IMGP;
+      img_ok = ((int)img - a.nimg) >> 31;  // all ones: the image exists (the last tile runs past the last one)
+      vbase = ((int)img < a.nimg ? (int)img : a.nimg) * a.HWY;
+    }
     const uint32_t oh = __umulhi(p, a.pw_m) >> a.pw_s;
     const int ow0 = (int)(p - oh * (uint32_t)a.PWp);
     const int inside = ((int)oh - a.OH) >> 31;  // all ones: the row exists
@@ -220,8 +232,18 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     v = v > span ? span : v;
     const int owc = ow0 < a.OW ? ow0 : a.OW;
     const int ohc = (int)oh < a.OH ? (int)oh : a.OH;
-    valid = v & inside;
-    return ohc * a.OW + (owc & inside);
+    valid = v & inside & img_ok;
+    return vbase + ((ohc * a.OW + (owc & inside)) & img_ok);
+  };
+  // element offset of virtual compact index v of channel row m inside y (global mode: per lane, v / HWY by magic)
+  auto virt_to_y = [&](int v, int m, int& rem) __attribute__((always_inline)) -> size_t {
+    if (!a.glob) {
+      rem = 0;
+      return (size_t)m * (uint32_t)a.HWY + v;
+    }
+    const uint32_t img = __umulhi((uint32_t)v, a.hwy_m) >> a.hwy_s;
+    rem = v - (int)img * a.HWY;
+    return ((size_t)img * a.M + m) * (uint32_t)a.HWY + rem;
   };
 
   auto epilogue = [&](int b, int p0, int mt) __attribute__((always_inline)) {  // (mt: an opaque copy, see the call)
@@ -271,6 +293,30 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3])::"memory");
         // whole 16-byte pieces, then the row's tail (len % 16 bytes, the same for every row: wave-uniform decisions)
         const int off = (lane & 7) * 16, tail = len & 15, toff = len & ~15;
+        if (a.glob) {  // kernel-uniform: a piece may end in the next image (HWY = 49 bytes per image and channel): byte-wise there
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int m = mt * 32 + it * 8 + (lane >> 3);
+            const v4i v = rv[it];
+            const int cnt_ = len - off < 16 ? len - off : 16;
+            if (cnt_ > 0 && m < a.M) {
+              int rem;
+              int8_t* yp = reinterpret_cast<int8_t*>(a.y) + virt_to_y(d_a + off, m, rem);
+              const int n1 = a.HWY - rem < cnt_ ? a.HWY - rem : cnt_;  // bytes that stay in this image
+              if (n1 == 16) {
+                __builtin_memcpy(yp, &v, 16);
+              } else {
+                int8_t* yq = yp - rem + (size_t)a.M * (uint32_t)a.HWY;  // the same channel row of the next image
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                  const int8_t bv = (int8_t)((uint32_t)v[k >> 2] >> (8 * (k & 3)));
+                  if (k < n1) yp[k] = bv;
+                  else if (k < cnt_) yq[k - n1] = bv;
+                }
+              }
+            }
+          }
+        } else {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int m = mt * 32 + it * 8 + (lane >> 3);
@@ -303,6 +349,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
             }
           }
         }
+        }
         if (diag && nepi == 0 && lane == 0) lstamp[19 + 2 * gi] = __builtin_amdgcn_s_memtime();  // group's stores issued
       });
     } else {
@@ -320,7 +367,8 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
           if (v0_ == 0 && v1_ == 0) continue;  // wave-uniform
           const int valid = h ? v1_ : v0_, d = h ? d1_ : d0_;
           if (valid == 0 || mrow >= a.M) continue;
-          const size_t yoff = (size_t)b * a.y_bstride + (size_t)mrow * (uint32_t)a.HWY + d;
+          int rem_;
+          const size_t yoff = (size_t)b * a.y_bstride + virt_to_y(d, mrow, rem_);  // (a 4-pixel group never leaves its image)
           if constexpr (OUT == OUT_I32) {
             int* yp = reinterpret_cast<int*>(a.y) + yoff;
             if (valid == 4) {

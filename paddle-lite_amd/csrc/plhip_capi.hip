@@ -128,7 +128,9 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   if (g->impl == IMPL_IM2COL_GEMM &&
       plhip::conv_patch_supported(d->cin, d->cout, d->kh, d->kw, d->stride[0], d->stride[1], d->dil[0], d->dil[1], d->groups, d->w,
                                   d->pad[2], d->pad[3]) &&
-      patch_input_bytes(d) < ((size_t)1 << 31) - 4096 && g->oh >= 1) {
+      patch_input_bytes(d) < ((size_t)1 << 31) - 4096 && g->oh >= 1 &&
+      // (global mode, planes smaller than a tile: a 16-byte output piece may end in the NEXT image, not beyond it)
+      !(plhip::conv_patch_global(plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3])) && g->oh * g->ow < 16)) {
     g->impl = IMPL_PATCH_GEMM;
     return true;
   }
@@ -390,6 +392,8 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     pa.planes = d->n * d->cin;
     pa.h = d->h; pa.w = d->w; pa.ph = PH; pa.pw = PWp; pa.pt = d->pad[0]; pa.pl = d->pad[2];
     pa.total = (long)need;
+    pa.tb = plhip::conv_patch_global(PWp) ? d->n : 0;  // planes smaller than a tile: channel-major copy
+    pa.tc = d->cin;
     plhip::launch_pad_rows8(pa, ctx->stream);
     LAUNCHCHK(ctx, "pad_rows8");
     plhip::PatchArgs a;

@@ -50,6 +50,7 @@ struct PadArgs {
   int8_t* xp;       // [planes][ph][pw] + slack, zero border; stride 2: [planes][2][2][ph][pw] phase planes
   int planes, h, w, ph, pw, pt, pl;
   int stride;       // 1, or 2 = phase-split copy (ph, pw are then the phase plane's dims)
+  int tb, tc;       // pad_rows8 only, tb > 0: CHANNEL-major output: plane c * tb + b of xp <- plane b * tc + c of x
   long total;       // bytes of xp to write (multiple of 4: planes*ph*pw rounded up + slack)
   // exact division of a 31-bit index by ph*pw and by pw without a divide sequence (launch_pad_input fills them; same
   // (magic, shift) form as DwArgs: magic == 0 -> power of two)
@@ -84,11 +85,16 @@ struct PatchArgs {
   int8_t* y2;
   float inv_scale2;
   int dbg;
+  // global mode (planes smaller than a tile: 7-wide): the padded copy is [c][image][PH][PWp], p runs over all images
+  int glob, nimg, IMGP;  // nimg = the real image count; IMGP = PH * PWp pixels per image (PLANE is then the CHANNEL stride B * IMGP, B = 1, TPI = T)
+  unsigned imgp_m, hwy_m;
+  int imgp_s, hwy_s;
   int delay;           // NH = 1: s_sleep units the second block of a CU starts late (experiments)
   unsigned long long* stamps;
 };
 // row pitch of the padded copy for (w, pl, pr), 0 = outside the route
 int conv_patch_row_pitch(int w, int pl, int pr);
+bool conv_patch_global(int pwp);  // planes smaller than a tile: channel-major padded copy, p across images
 bool conv_patch_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int w, int pl, int pr);
 size_t conv_patch_packed_bytes(int cin, int cout);
 void launch_pack_conv_patch(const int8_t* w_oihw, int8_t* wp, int cin, int cout, hipStream_t s);

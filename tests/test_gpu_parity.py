@@ -349,7 +349,11 @@ def test_patch_conv_route(gpu_ctx, pkg, plref):
         (37, 64, 14, 14, 96, (1, 1, 1, 1), 1), (1, 64, 40, 58, 130, (1, 1, 1, 1), 4),
         # more tiles than tile streams (512): every stream works through two tiles (the ring, the DMA cursor and the
         # register-resident weights across a tile boundary), in each of the three kernel variants
-        (530, 64, 6, 14, 96, (1, 1, 1, 1), 1), (530, 64, 6, 14, 32, (1, 1, 1, 1), 2), (530, 128, 6, 14, 72, (1, 1, 1, 1), 0)]
+        (530, 64, 6, 14, 96, (1, 1, 1, 1), 1), (530, 64, 6, 14, 32, (1, 1, 1, 1), 2), (530, 128, 6, 14, 72, (1, 1, 1, 1), 0),
+        # 7-wide planes (row pitch 8): global mode — channel-major padded copy, tiles across images, output pieces that end
+        # in the next image; batch 1 (less than a tile), odd batches, all three kernel variants, asymmetric pads
+        (1, 64, 7, 7, 96, (1, 1, 1, 1), 1), (9, 64, 7, 7, 64, (1, 1, 1, 1), 2), (5, 512, 7, 7, 520, (1, 1, 1, 1), 1),
+        (13, 96, 9, 6, 72, (1, 0, 1, 1), 0), (7, 64, 5, 5, 130, (2, 1, 2, 1), 4), (70, 128, 7, 7, 96, (1, 1, 1, 1), 1)]
     for (n, cin, h, w, cout, pads, act) in cases:
         d = capi.conv_desc(n, cin, h, w, cout, 3, 3, pads, (1, 1), (1, 1), 1, act, 0.0)
         assert gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) == b"conv_patch_gemm_int8_mfma32x32x32", (cin, cout, w, pads)
@@ -400,12 +404,12 @@ def test_patch_conv_random_shapes(gpu_ctx, pkg, plref):
         cout = int(rng.integers(32, 301))
         if cout <= 64 and cin != 64:
             cout += 64
-        n, h, w = int(rng.integers(1, 10)), int(rng.integers(6, 61)), int(rng.integers(6, 61))
+        n, h, w = int(rng.integers(1, 10)), int(rng.integers(4, 61)), int(rng.integers(4, 61))
         pads = tuple(int(v) for v in rng.integers(0, 3, 4))
         act = int(rng.choice([0, 1, 2, 4]))
         d = capi.conv_desc(n, cin, h, w, cout, 3, 3, pads, (1, 1), (1, 1), 1, act, 0.0)
         if gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) != b"conv_patch_gemm_int8_mfma32x32x32":
-            continue  # (row pitch outside 16..64)
+            continue  # (row pitch outside 8..64)
         if n * cout * h * w * cin > 6e9 / 9:
             continue  # keep the scalar oracle in seconds
         done += _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 3, 3, pads, 1, 1, 1, act, 6.0 if act == 2 else 0.25,

@@ -35,7 +35,9 @@ python tools/pmc_sq.py $O/sq_c4 $O/pmc_sq_c4.csv > /dev/null || exit 1
 timeout -k 10 200 python tools/opbench.py all 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench.txt || exit 1
 timeout -k 10 200 python tools/opbench.py all --batch 256 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench_b256.txt || exit 1
 PLHIP_GEMM_WIDE=0 timeout -k 10 200 python tools/opbench.py pw 2>&1 | cut -c1-110 > $O/opbench_pw_wide_off.txt || exit 1
-for l in pw8 pw6 pw13 pw14; do PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/wide_timeline.py $l > $O/wide_timeline_$l.txt 2>&1 || exit 1; done
+for l in pw8 pw6 pw13; do PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/wide_timeline.py $l > $O/wide_timeline_$l.txt 2>&1 || exit 1; done
+# (pw14 has an fp32 output: it runs on the ring kernels by default; its wide-kernel timeline needs the tile forced)
+PLHIP_WIDE_NTT=4 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/wide_timeline.py pw14 > $O/wide_timeline_pw14.txt 2>&1 || exit 1
 PLHIP_GEMM_WIDE=0 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/gemm_timeline.py pw8 > $O/gemm_timeline_pw8_ring.txt 2>&1 || exit 1
 # the patch kernel (conv_patch_i8.hip): config #2 and ResNet50's 3x3 layers, A/B against the ring kernel's implicit GEMM, the
 # in-kernel timelines, the time without the epilogue, and the depthwise 5x5 rows
