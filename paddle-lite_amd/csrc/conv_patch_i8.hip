@@ -70,6 +70,7 @@ bool conv_patch_supported(int cin, int cout, int kh, int kw, int sh, int sw, int
   const int pwp = conv_patch_row_pitch(w, pl, pr);
   if (pwp > 64 || pwp < 8) return false;
   if (cout <= 64 && cin != 64) return false;  // the 2 x 2 wave layout exists for the register-resident weights only
+  if (cout <= 64 && conv_patch_global(pwp)) return false;  // ... and not in global mode (no registers for its second epilogue body)
   return true;
 }
 

@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   // ([c][image][PH][PWp]), so for one channel the images follow each other and p runs over all of them, IMGP pixels each;
   // the value returned is then a VIRTUAL compact index img * HWY + oh * OW + ow (still monotone in p); virt_to_y maps it
   // to the output element (images are M * HWY apart for one channel).
-  auto dst_of = [&](uint32_t p, int& valid, int span) __attribute__((always_inline)) -> int {
+  auto dst_of = [&](auto glob_c, uint32_t p, int& valid, int span) __attribute__((always_inline)) -> int {
     int vbase = 0, img_ok = -1;
-    if (a.glob) {  // kernel-uniform
+    if constexpr (decltype(glob_c)::value) {
       const uint32_t img = __umulhi(p, a.imgp_m) >> a.imgp_s;
       p -= img * (uint32_t)a.IMGP;
       img_ok = ((int)img - a.nimg) >> 31;  // all ones: the image exists (the last tile runs past the last one)
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     return vbase + ((ohc * a.OW + (owc & inside)) & img_ok);
   };
   // element offset of virtual compact index v of channel row m inside y (global mode: per lane, v / HWY by magic)
-  auto virt_to_y = [&](int v, int m, int& rem) __attribute__((always_inline)) -> size_t {
-    if (!a.glob) {
+  auto virt_to_y = [&](auto glob_c, int v, int m, int& rem) __attribute__((always_inline)) -> size_t {
+    if constexpr (!decltype(glob_c)::value) {
       rem = 0;
       return (size_t)m * (uint32_t)a.HWY + v;
     }
@@ -246,7 +246,10 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     return ((size_t)img * a.M + m) * (uint32_t)a.HWY + rem;
   };
 
-  auto epilogue = [&](int b, int p0, int mt) __attribute__((always_inline)) {  // (mt: an opaque copy, see the call)
+  // GLOB (global mode) is a compile-time property of the epilogue: a kernel-uniform test per geometry call cost the other
+  // layers 5-10 % (config #2 20.3 -> 22.5 us, measured on one box against the build before)
+  auto epilogue = [&](auto glob_c, int b, int p0, int mt) __attribute__((always_inline)) {  // (mt: an opaque copy, see the call)
+    constexpr bool GLOB = decltype(glob_c)::value;
     const int pw0 = p0 + wn * (NTW * 32);  // first pixel of my n tiles (wave-uniform: so is every dst_of below -> scalar unit)
     const int mrow = mt * 32 + c;
     const float bi_ = a.bias ? bi : 0.f;
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         constexpr int gi = decltype(g_c)::value;
         constexpr int nt0 = gi * 4, cnt = gi == 0 ? 4 : NTW - 4;
         int dummy;
-        const int d_a = dst_of((uint32_t)(pw0 + 32 * nt0), dummy, 0);
-        const int d_b = dst_of((uint32_t)(pw0 + 32 * (nt0 + cnt)), dummy, 0);
+        const int d_a = dst_of(glob_c, (uint32_t)(pw0 + 32 * nt0), dummy, 0);
+        const int d_b = dst_of(glob_c, (uint32_t)(pw0 + 32 * (nt0 + cnt)), dummy, 0);
         patch_static_for<0, cnt>([&](auto t_c) __attribute__((always_inline)) {
           constexpr int t = decltype(t_c)::value;
           const v4i ch = NONNEG ? tr_requant_chunk<ACT_RELU>(acc[nt0 + t], s2, b2, leak, lo2, hi2)
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {  // pixel order; lanes of half k >> 1 hold piece k
             int valid;
-            const int d = dst_of((uint32_t)(pw0 + 32 * (nt0 + t) + 8 * k), valid, 8);  // scalar
+            const int d = dst_of(glob_c, (uint32_t)(pw0 + 32 * (nt0 + t) + 8 * k), valid, 8);  // scalar
             // a dropped piece goes to the spare 8 bytes at the end of the row (no branch: a pipeline bubble per piece)
             const uint32_t wa_ = wrow + (uint32_t)(valid > 0 ? d - d_a : PATCH_SP - 8);
             const unsigned long long m = (k >> 1) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3])::"memory");
         // whole 16-byte pieces, then the row's tail (len % 16 bytes, the same for every row: wave-uniform decisions)
         const int off = (lane & 7) * 16, tail = len & 15, toff = len & ~15;
-        if (a.glob) {  // kernel-uniform: a piece may end in the next image (HWY = 49 bytes per image and channel): byte-wise there
+        if constexpr (GLOB) {  // a piece may end in the next image (HWY = 49 bytes per image and channel): byte-wise there
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int m = mt * 32 + it * 8 + (lane >> 3);
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
             const int cnt_ = len - off < 16 ? len - off : 16;
             if (cnt_ > 0 && m < a.M) {
               int rem;
-              int8_t* yp = reinterpret_cast<int8_t*>(a.y) + virt_to_y(d_a + off, m, rem);
+              int8_t* yp = reinterpret_cast<int8_t*>(a.y) + virt_to_y(glob_c, d_a + off, m, rem);
               const int n1 = a.HWY - rem < cnt_ ? a.HWY - rem : cnt_;  // bytes that stay in this image
               if (n1 == 16) {
                 __builtin_memcpy(yp, &v, 16);
@@ -362,13 +365,13 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           int v0_, v1_;
-          const int d0_ = dst_of((uint32_t)(pw0 + 32 * t + 8 * gq), v0_, 4);
-          const int d1_ = dst_of((uint32_t)(pw0 + 32 * t + 8 * gq + 4), v1_, 4);
+          const int d0_ = dst_of(glob_c, (uint32_t)(pw0 + 32 * t + 8 * gq), v0_, 4);
+          const int d1_ = dst_of(glob_c, (uint32_t)(pw0 + 32 * t + 8 * gq + 4), v1_, 4);
           if (v0_ == 0 && v1_ == 0) continue;  // wave-uniform
           const int valid = h ? v1_ : v0_, d = h ? d1_ : d0_;
           if (valid == 0 || mrow >= a.M) continue;
           int rem_;
-          const size_t yoff = (size_t)b * a.y_bstride + virt_to_y(d, mrow, rem_);  // (a 4-pixel group never leaves its image)
+          const size_t yoff = (size_t)b * a.y_bstride + virt_to_y(glob_c, d, mrow, rem_);  // (a 4-pixel group never leaves its image)
           if constexpr (OUT == OUT_I32) {
             int* yp = reinterpret_cast<int*>(a.y) + yoff;
             if (valid == 4) {
@@ -581,7 +584,10 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
       // and offsets would sit in registers for the whole tile)
       int be = b, pe = p0, me = mt;
       asm volatile("" : "+s"(be), "+s"(pe), "+s"(me));
-      epilogue(be, pe, me);
+      // (the 2 x 2 layout has no registers to spare for a second epilogue body: conv_patch_supported keeps 7-wide planes with
+      // M <= 64 on the ring kernel)
+      if (WNH == 1 && a.glob) epilogue(std::true_type{}, be, pe, me);  // kernel-uniform
+      else epilogue(std::false_type{}, be, pe, me);
       ++nepi;
     }
     if (nstamp < PATCH_STAMP_SLOTS - 3) {

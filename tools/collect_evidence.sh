@@ -8,8 +8,13 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/evidence
-rm -rf $O && mkdir -p $O
+# PART=1: the rocprofv3 passes; PART=2: tables, timelines and bench lines (each half stays under gpurun's 20-minute limit);
+# default: both
+PART=${PART:-all}
+if [ "$PART" != "2" ]; then rm -rf $O; fi
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+if [ "$PART" != "2" ]; then
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU"
 B="--no-cpu-baseline --no-selfcheck --windows 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_default -o p --output-format csv -- python $R/bench.py $B --steps 30 > $O/bench_under_rocprof_default.json 2> $O/stats_default.err || exit 1
@@ -32,6 +37,9 @@ echo "sq done"
 cd $R
 python tools/pmc_sq.py $O/sq_c3 $O/pmc_sq_c3.csv > /dev/null || exit 1
 python tools/pmc_sq.py $O/sq_c4 $O/pmc_sq_c4.csv > /dev/null || exit 1
+fi
+if [ "$PART" = "1" ]; then exit 0; fi
+cd $R
 timeout -k 10 200 python tools/opbench.py all 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench.txt || exit 1
 timeout -k 10 200 python tools/opbench.py all --batch 256 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench_b256.txt || exit 1
 PLHIP_GEMM_WIDE=0 timeout -k 10 200 python tools/opbench.py pw 2>&1 | cut -c1-110 > $O/opbench_pw_wide_off.txt || exit 1
@@ -58,6 +66,6 @@ timeout -k 10 400 python bench.py --config c4 --layer-table > $O/bench_c4.json 2
 timeout -k 10 400 python bench.py --config c5 --layer-table > $O/bench_c5.json 2> $O/layer_table_c5.txt || exit 1
 timeout -k 10 300 python bench.py --config c2 > $O/bench_c2.json 2>/dev/null || exit 1
 # the N > 1 data path on one GPU: one rank, RCCL broadcast / scatter / per-step all_gather
-PLHIP_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_force_dist.json 2>/dev/null || exit 1
+PLHIP_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_force_dist.json 2> $O/force_dist.err || { tail -5 $O/force_dist.err; exit 1; }
 timeout -k 10 100 python tools/c2bench.py > $O/c2bench.txt 2>&1 || exit 1
 tail -c 400 $O/bench.json
