@@ -174,6 +174,148 @@ void launch_pad_rows8(PadArgs a, hipStream_t s) {  // a.pw % 8 == 0, a.total % 1
   hipLaunchKernelGGL(pad_rows8_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
+// ---- 3x3 STRIDE 2 over phase planes (ResNet50's three downsampling 3x3 convs).
+// With xpad = the zero-padded input, phase plane P_ab[i][j] = xpad[2i + a][2j + b]:
+//   out[oh][ow] = sum w[r][s] xpad[2 oh + r][2 ow + s] = sum w[r][s] P_{r&1, s&1}[oh + (r >> 1)][ow + (s >> 1)],
+// i.e. on phase plane (0,0) a 2x2 stride-1 conv, on (0,1) a 2x1, on (1,0) a 1x2 and on (1,1) a 1x1 one: the patch kernel's slab
+// walk with 6 slabs per 32 channels (plane, column shift) of 2 / 1 tap rows (conv_patch_kernel.h, patch_s2_*) instead of 3
+// slabs of 3.  (The dense 2x2 form over 4 Cin "channels" (c, a, b) multiplies 7 zero taps in 16 and measured no faster than
+// the ring kernel.)  Row pitch of a phase plane: a multiple of 8 >= ceil((W + pads) / 2); the copy's planes are ordered
+// [image][group of 32 channels][phase 2a + b][channel % 32]: a "chunk" of the kernel = the 32 channels of one phase.
+int conv_patch_s2_row_pitch(int w, int pl, int pr) { return (((w + pl + pr + 1) >> 1) + 7) & ~7; }
+bool conv_patch_s2_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int w, int pl, int pr) {
+  if (!patch_env()) return false;
+  static int s2_env = -1;
+  if (s2_env < 0) {
+    const char* e = getenv("PLHIP_CONV_PATCH_S2");  // 0 = the ring kernel's stride-2 implicit GEMM (A/B runs)
+    s2_env = e ? atoi(e) : 1;
+  }
+  if (!s2_env) return false;
+  if (kh != 3 || kw != 3 || sh != 2 || sw != 2 || dh != 1 || dw != 1 || groups != 1) return false;
+  if (cin % 32 != 0 || cout <= 64) return false;  // whole 32-channel groups; the 4 x 1 wave layout
+  const int pwp = conv_patch_s2_row_pitch(w, pl, pr);
+  return pwp <= 64 && pwp >= 8;
+}
+size_t conv_patch_s2_packed_bytes(int cin, int cout) { return (size_t)((cout + 31) / 32) * (cin / 32) * 9 * 1024; }
+
+// weights [m tile][group of 32 channels][9 fragments in step order][64 lanes][16 B]: lane (m % 32, h) holds channels
+// 16h .. 16h + 15 of the group; fragment f = patch_s2_wfrag(ls) + r' <-> tap (2 r' + a, 2 s' + b) of step ls
+__global__ void pack_conv_patch_s2_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp, int cin, int cout, size_t total) {
+  const int NG = cin / 32;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = idx & 15;
+    const int lane = (idx >> 4) & 63;
+    size_t t = idx >> 10;
+    const int f = t % 9;
+    t /= 9;
+    const int g = t % NG;
+    const int mt = (int)(t / NG);
+    int ls = 0;
+    while (ls < 5 && patch_s2_wfrag(ls + 1) <= f) ++ls;
+    const int r1 = f - patch_s2_wfrag(ls), ph = patch_s2_phase(ls);
+    const int r = 2 * r1 + (ph >> 1), sx = 2 * patch_s2_shift(ls) + (ph & 1);
+    const int m = mt * 32 + (lane & 31);
+    const int c = g * 32 + 16 * (lane >> 5) + j;
+    wp[idx] = m < cout ? w[(((size_t)m * cin + c) * 3 + r) * 3 + sx] : (int8_t)0;
+  }
+}
+void launch_pack_conv_patch_s2(const int8_t* w_oihw, int8_t* wp, int cin, int cout, hipStream_t s) {
+  const size_t total = conv_patch_s2_packed_bytes(cin, cout);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_patch_s2_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, wp, cin, cout, total);
+}
+
+// phase-split zero-padded copy: output plane (b, g, phase 2a + b', c32) [ph][pw] = x[b][32 g + c32][2 ph + a - pt][2 pw + b' - pl]
+// or 0; a.planes = B * 4 C output planes, a.tc = 4 C, a.ph / a.pw the phase plane's dims (pw % 8 == 0).  One thread = 16 output
+// bytes = two 8-byte halves, each inside one output row.  A half = every other byte of a 15-byte source span: ONE unaligned
+// 16-byte fetch at the span's address wherever that lies inside the input buffer — also when the span starts left of the row
+// or ends right of it (the 14-wide planes: every span does): the bytes of the neighbouring rows it brings along are masked
+// off — and byte loads only at the two ends of the buffer.  (First version: byte loads for every span that crossed a row
+// border, half of all spans at 56 x 56 and all of them at 14 x 14: 0.5-1.5 TB/s.)
+// a.tb > 0: channel-major output (global mode), as pad_rows8_i8_kernel; div_pwq: the divisor a.tb.
+__global__ __launch_bounds__(256) void pad_phase8_i8_kernel(PadArgs a) {
+  const long nq = a.total >> 4;
+  const uint32_t plane_sz = (uint32_t)a.ph * (uint32_t)a.pw;
+  const long xbytes = (long)(a.planes >> 2) * a.h * a.w;
+  const long nbx = (gridDim.x + 7) >> 3;
+  const long vb = (long)(blockIdx.x & 7) * nbx + (blockIdx.x >> 3);
+  for (long q = vb * blockDim.x + threadIdx.x; q < nq; q += 8 * nbx * blockDim.x) {
+    unsigned long long out[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const uint32_t o = ((uint32_t)q << 4) + 8u * e;
+      const uint32_t plane = fastdiv_u31(o, a.div_plane_m, a.div_plane_s);
+      const uint32_t rem = o - plane * plane_sz;
+      const bool inside = (int)plane < a.planes;
+      uint32_t b_, ce;  // image, (group, phase, channel % 32)
+      if (a.tb > 0) {
+        ce = fastdiv_u31(plane, a.div_pwq_m, a.div_pwq_s);
+        b_ = plane - ce * (uint32_t)a.tb;
+      } else {
+        b_ = fastdiv_u31(plane, a.div_ph_m, a.div_ph_s);
+        ce = plane - b_ * (uint32_t)a.tc;
+      }
+      const uint32_t src_plane = b_ * ((uint32_t)a.tc >> 2) + (ce >> 7) * 32u + (ce & 31u);
+      const int pa = (ce >> 6) & 1, pb = (ce >> 5) & 1;
+      const int ph = (int)fastdiv_u31(rem, a.div_pw_m, a.div_pw_s), pc = (int)rem - ph * a.pw;
+      const int ih = 2 * ph + pa - a.pt, iw0 = 2 * pc + pb - a.pl;  // source row; source column of output byte 0 (then + 2 per byte)
+      unsigned long long v = 0;
+      if (inside && ih >= 0 && ih < a.h && iw0 < a.w && iw0 + 15 > 0) {
+        const long off = ((long)src_plane * a.h + ih) * a.w + iw0;
+        if (off >= 0 && off + 16 <= xbytes) {
+          uint32_t dd[4];
+          __builtin_memcpy(dd, a.x + off, 16);
+          v = (unsigned long long)__builtin_amdgcn_perm(dd[1], dd[0], 0x06040200u) |
+              ((unsigned long long)__builtin_amdgcn_perm(dd[3], dd[2], 0x06040200u) << 32);
+          // output bytes [k0, k1) come from columns inside the row
+          const int k0 = iw0 < 0 ? (1 - iw0) >> 1 : 0;
+          const int k1 = (a.w - iw0 + 1) >> 1;  // >= 1
+          if (k0 > 0) v &= ~0ull << (8 * k0);
+          if (k1 < 8) v &= ~(~0ull << (8 * k1));
+        } else {
+          const int8_t* row = a.x + (off - iw0);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int iw = iw0 + 2 * k;
+            if (iw >= 0 && iw < a.w) v |= (unsigned long long)(uint8_t)row[iw] << (8 * k);
+          }
+        }
+      }
+      out[e] = v;
+    }
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 o2 = {out[0], out[1]};
+    reinterpret_cast<v2u64*>(a.xp)[q] = o2;
+  }
+}
+void launch_pad_phase8(PadArgs a, hipStream_t s) {  // a.pw % 8 == 0, a.total % 16 == 0, a.xp 16-byte aligned, a.tc = 4 C
+  unsigned m;
+  int sh;
+  auto magic = [&](long d) {
+    int l = 0;
+    while ((1L << l) < d) ++l;
+    if ((1L << l) == d) {
+      m = 0;
+      sh = l;
+    } else {
+      m = (unsigned)(((1ULL << (31 + l)) / (unsigned long long)d) + 1ULL);
+      sh = l - 1;
+    }
+  };
+  magic((long)a.ph * a.pw);
+  a.div_plane_m = m; a.div_plane_s = sh;
+  magic(a.pw);
+  a.div_pw_m = m; a.div_pw_s = sh;
+  magic(a.tc);
+  a.div_ph_m = m; a.div_ph_s = sh;
+  magic(a.tb > 0 ? a.tb : 1);
+  a.div_pwq_m = m; a.div_pwq_s = sh;
+  long blocks = ((a.total >> 4) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  blocks = (blocks + 7) & ~7L;
+  hipLaunchKernelGGL(pad_phase8_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
 // fastdiv_u31's (magic, shift) for divisor d (dw_common.h); general_pow2: the multiply form for powers of two as well
 // (d >= 2: magic 2^31 + 1, shift l - 1), for device code that must not branch on the marker 0
 static inline void magic_u31(long d, unsigned& m, int& sh, bool general_pow2 = false) {
@@ -201,8 +343,8 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   a.NCH = a.C / 32;
   a.HWY = a.OH * a.OW;
   a.y_bstride = (size_t)a.M * a.HWY;
-  const bool stat = a.NCH == 2;
-  const bool layout_b = a.M <= 64;                // 2 m tiles x 2 pixel groups per half (else 4 x 1)
+  const bool stat = a.NCH == 2 && !a.s2;
+  const bool layout_b = a.M <= 64 && !a.s2;       // 2 m tiles x 2 pixel groups per half (else 4 x 1)
   const int NTH = (layout_b ? 2 : 1) * PATCH_NTW * 32;
   const int WMH = layout_b ? 2 : 4;
   a.glob = conv_patch_global(a.PWp) ? 1 : 0;
@@ -220,7 +362,8 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   a.T = a.B * a.TPI;
   magic_u31(a.IMGP, a.imgp_m, a.imgp_s, true);
   magic_u31(a.HWY > 1 ? a.HWY : 2, a.hwy_m, a.hwy_s, true);
-  int pitch = (NTH + 2 * a.PWp + 31) & ~31;
+  const int KT = a.s2 ? 2 : 3;  // tap rows a slab is read at (stride 2: phase planes, at most 2)
+  int pitch = (NTH + (KT - 1) * a.PWp + 31) & ~31;
   if (((pitch >> 5) & 1) == 0) pitch += 32;
   a.pitch = pitch;
   a.pps = pitch >> 5;
@@ -244,7 +387,8 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   magic_u31(a.PWp, a.pw_m, a.pw_s, true);
   magic_u31(a.TPI, a.tpi_m, a.tpi_s);
   magic_u31(a.pitch, a.pitch_m, a.pitch_s);
-  if (layout_b) launch_patch_stat_b(a, out, s);
+  if (a.s2) launch_patch_s2(a, out, s);
+  else if (layout_b) launch_patch_stat_b(a, out, s);
   else if (stat) launch_patch_stat_a(a, out, s);
   else launch_patch_stream_a(a, out, s);
 }

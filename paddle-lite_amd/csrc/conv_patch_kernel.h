@@ -36,10 +36,36 @@ __device__ __forceinline__ void patch_static_for(F&& f) {
 // both multiply, then both requantise: profiles/r03_patch_timeline_v1_c2.txt).  NH = 2: one 8-wave block per CU whose slab
 // pair shares the weight fragments of its (chunk, shift) through the ring.  NPW DMA pieces per wave and slot; NSLOT ring
 // slots; STAT: the whole K of the weights stays in registers (C = 64), else they travel through the ring.
-template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT, bool NONNEG>
+// KT: 3 = stride 1: per 32-channel chunk 3 slabs (column shifts) of 3 tap rows.  2 = a 3x3 STRIDE-2 conv over the 4 phase
+// planes of every channel (conv_patch_i8.hip; weights through the ring only): the "chunks" of the padded copy are (group of 32
+// channels, phase), and a group is walked in 6 steps of 2 / 1 / 2 / 1 / 2 / 1 tap rows (PATCH_S2_* below): the 9 taps once.
+// stride 2, step ls of a group: phase plane (a, b) = (row, column parity) of the padded input, its column shift s' and tap
+// rows r' < ROWS <-> taps (2 r' + a, 2 s' + b); first weight fragment of the step among the group's 9
+//   ls      0      1      2      3      4      5
+//   phase  (0,0)  (1,0)  (0,0)  (1,0)  (0,1)  (1,1)
+//   s'      0      0      1      1      0      0
+//   rows    2      1      2      1      2      1        (2-row and 1-row steps alternate: every pair of steps is 21 MFMAs)
+__host__ __device__ constexpr int patch_s2_phase(int ls) { return (0x312020 >> (4 * ls)) & 15; }  // 2 a + b
+__host__ __device__ constexpr int patch_s2_shift(int ls) { return (ls == 2 || ls == 3) ? 1 : 0; }
+__host__ __device__ constexpr int patch_s2_rows(int ls) { return (ls & 1) ? 1 : 2; }
+__host__ __device__ constexpr int patch_s2_wfrag(int ls) { return (0x865320 >> (4 * ls)) & 15; }
+
+// DMA pieces per wave of the slot of step ls, and their sum over steps [ls0, ls1)
+template <int KT, int NPW>
+__host__ __device__ constexpr int patch_npws(int ls) { return KT == 3 ? NPW : NPW - ((ls % 6) & 1); }
+template <int KT, int NPW>
+__host__ __device__ constexpr int patch_npws_sum(int ls0, int ls1) {
+  int n = 0;
+  for (int l = ls0; l < ls1; ++l) n += patch_npws<KT, NPW>(l);
+  return n;
+}
+
+template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT, bool NONNEG, int KT = 3>
 __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a) {
+  static_assert(KT == 3 || (KT == 2 && !STAT && NH == 2 && WMH == 4 && (NSLOT - 1) % 2 == 0), "taps");
+  constexpr int SPG = KT == 3 ? 3 : 6;  // steps per chunk (stride 2: per group of 4 phase chunks)
   constexpr int NTW = PATCH_NTW, NTH = WNH * NTW * 32, D = NSLOT - 1, NW = 4 * NH;
-  constexpr int WPIECES = STAT ? 0 : 3 * WMH;  // 1-KiB weight pieces of a slot
+  constexpr int WPIECES = STAT ? 0 : KT * WMH;  // 1-KiB weight pieces of a slot
   static_assert(WMH * WNH == 4 && NSLOT >= 3 && NSLOT <= 4 && (NH == 1 || NH == 2), "layout");
   PLHIP_PRELOAD(a.xp); PLHIP_PRELOAD(a.wp); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias);
   PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.M); PLHIP_PRELOAD(a.OH); PLHIP_PRELOAD(a.OW); PLHIP_PRELOAD(a.PWp); PLHIP_PRELOAD(a.PLANE);
@@ -84,7 +110,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   const int mrow = mt * 32 + c;
   const int SLAB = 32 * a.pitch;
   const int SLOTB = NH * SLAB + WPIECES * 1024;
-  const int NCH = a.NCH;
+  const int NCH = KT == 3 ? a.NCH : a.NCH >> 2;  // K loop: chunks (stride 2: groups of 32 channels = 4 phase chunks)
 
   // ---- this lane's scale / bias: the two oldest loads of the wave, inline asm like every load here (the compiler would
   // guard an ordinary load with vmcnt(0) at its first use, the epilogue, and drain the DMA pipeline there); every counted
@@ -128,11 +154,24 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
       int iw = wave + NW * j;
       if (iw >= WPIECES) iw -= NW;
       if (iw >= WPIECES) iw = 0;
-      const int mtl = iw / 3, r = iw - mtl * 3;
+      const int mtl = iw / KT, r = iw - mtl * KT;
       int mtw = mb * WMH + mtl;
       mtw = mtw < MT32 ? mtw : MT32 - 1;
       pwi[j] = iw;
       pwoff[j] = (uint32_t)((mtw * NCH * 9 + r) * 1024);
+    }
+  }
+  // stride 2, the 1-row steps: 2 pps activation pieces + WMH weight pieces fit the NPA activation slots of the 8 waves: the slot
+  // i = wave + NW (NPA - 1) >= 2 pps is weight piece i - 2 pps (m tile i - 2 pps, the step's one tap row) there
+  int w1i = -1;          // wave-uniform
+  uint32_t pw1off = 0;
+  if constexpr (KT == 2) {
+    const int i1 = wave + NW * (NPA - 1) - NH * a.pps;
+    if (i1 >= 0 && i1 < WMH) {
+      w1i = i1;
+      int mtw = mb * WMH + i1;
+      mtw = mtw < MT32 ? mtw : MT32 - 1;
+      pw1off = (uint32_t)(mtw * NCH * 9 * 1024);
     }
   }
   const uint32_t lane16 = (uint32_t)lane * 16u;
@@ -164,11 +203,16 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     }
   };
   // one DMA piece j of the slot (chunk ic, shift is) -> ring slot `slot`; j < NPA: activations, then weights
+  // (stride 2: `is` is the step index inside the group, a compile-time constant at every call site)
   auto issue_piece = [&](auto j_c, const uint8_t* const (&tb)[NH], int ic, int is, int slot) __attribute__((always_inline)) {
     constexpr int j = decltype(j_c)::value;
     uint8_t* sb = ring + slot * SLOTB;
+    const int chunk = KT == 3 ? ic : ic * 4 + patch_s2_phase(is);
+    const int shift = KT == 3 ? is : patch_s2_shift(is);
+    const int wfrag = KT == 3 ? ic * 9 + is * 3 : ic * 9 + patch_s2_wfrag(is);
+    const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.wp) + (size_t)wfrag * 1024;
     if constexpr (j < NPA) {
-      const size_t coff = (size_t)(ic * 32) * (uint32_t)a.PLANE + is;
+      const size_t coff = (size_t)(chunk * 32) * (uint32_t)a.PLANE + shift;
       const uint8_t* sbase = (NH == 2 && pai[j] >= a.pps ? tb[NH - 1] : tb[0]) + coff;  // wave-uniform
       uint32_t vo;
       if constexpr (PVO_KEPT) {
@@ -178,29 +222,38 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         asm volatile("" : "+v"(ln));  // (opaque: not hoisted back out of the loop)
         vo = piece_offset(pai[j], ln);
       }
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(sbase + vo), (lds_ptr_t)(sb + pai[j] * 1024), 16, 0, 0);
+      const uint8_t* src = sbase + vo;
+      uint8_t* dst = sb + pai[j] * 1024;
+      if constexpr (KT == 2 && j == NPA - 1) {
+        if (patch_s2_rows(is) == 1 && w1i >= 0) {  // wave-uniform; selects, not a branch
+          src = wsrc + pw1off + lane16;
+          dst = sb + NH * SLAB + w1i * (KT * 1024);
+        }
+      }
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
     } else {
-      const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.wp) + (size_t)(ic * 9 + is * 3) * 1024;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc + pwoff[j - NPA] + lane16), (lds_ptr_t)(sb + NH * SLAB + pwi[j - NPA] * 1024), 16, 0, 0);
     }
   };
-  auto issue = [&](int ic, int is, int slot) __attribute__((always_inline)) {
+  // pieces per wave of the slot of step ls (stride 2: the 1-row steps have no piece NPW - 1)
+  auto issue = [&](int ic, auto is_c, int slot) __attribute__((always_inline)) {
+    constexpr int is = decltype(is_c)::value;
     const uint8_t* tb[NH];
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) tb[hf] = cb[hf];
-    patch_static_for<0, NPW>([&](auto j_c) __attribute__((always_inline)) { issue_piece(j_c, tb, ic, is, slot); });
+    patch_static_for<0, patch_npws<KT, NPW>(is)>([&](auto j_c) __attribute__((always_inline)) { issue_piece(j_c, tb, ic, is, slot); });
   };
 
   // ---- fragment addresses: lane 2q'+p of a 16-lane group -> channel row q', 8-byte sub-chunk p; group parity -> 16-pixel
   // chunk; k half h -> channels 16h .. 16h+15 (lo: +0..7, hi: +8..15)
   const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring;
   const uint32_t fa = ring_addr + half * SLAB + (16 * h + ((lane & 15) >> 1)) * a.pitch + wn * (NTW * 32) + ((lane >> 4) & 1) * 16 + (lane & 1) * 8;
-  const uint32_t wa = ring_addr + NH * SLAB + (wm * 3) * 1024 + lane * 16;
+  const uint32_t wa = ring_addr + NH * SLAB + (wm * KT) * 1024 + lane * 16;
   const uint32_t pitch8 = 8u * (uint32_t)a.pitch;
 
   v16i acc[NTW];
   v2i flo[4], fhi[4];  // fragment ring: 3 reads ahead
-  v4i wr[3];           // weight fragments of the step (ring mode)
+  v4i wr[KT];          // weight fragments of the step (ring mode)
 
   // ---- epilogue constants
   const float hi2 = a.act == ACT_RELU6 ? fminf(a.alpha + a.alpha, 254.f) : 254.f;
@@ -427,7 +480,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   int nstep = 0;                 // steps done (diagnostic stamps of the first six)
   int iqk = 0, iqc = 0, iqs = 0; // issue cursor: the slab pair D steps ahead
   auto advance_cursor = [&]() __attribute__((always_inline)) {
-    if (++iqs == 3) {
+    if (++iqs == SPG) {
       iqs = 0;
       if (++iqc == NCH) {
         iqc = 0;
@@ -445,7 +498,11 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     constexpr int CH = decltype(ch_c)::value, SS = decltype(ss_c)::value, FIRST = decltype(first_c)::value;
     // my pieces of this slot have landed (counted: everything issued after them may still fly) ...
     constexpr int Q = CH * 3 + SS;
-    constexpr int REG = (D - 1) * NPW;
+    constexpr int ROWS = KT == 3 ? 3 : patch_s2_rows(SS);  // tap rows of this step
+    constexpr int LS = (SS + D) % SPG;                     // the step whose slot this one fills; stride 2: as many rows as this one
+    constexpr int NPI = patch_npws<KT, NPW>(LS);                          // DMA pieces this step issues
+    static_assert(KT == 3 || patch_s2_rows(LS) == ROWS, "lookahead");
+    constexpr int REG = patch_npws_sum<KT, NPW>(SS + 1, SS + D);
     constexpr int WAIT0 = (STAT && Q < D) ? (D - 1 - Q) * (NPW + 3) + (18 - 3 * D) + Q * NPW : REG;
     static_assert(WAIT0 >= REG && WAIT0 < 64, "vmcnt");
     if constexpr (STAT && Q < D) {
@@ -465,7 +522,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
     // ADDED to the MFMA time instead of hiding under it: profiles/r03_patch_decompose.txt.)
     int islot = slot + D;
     islot = islot >= NSLOT ? islot - NSLOT : islot;
-    const int qc = iqc, qs = iqs;
+    const int qc = iqc, qs = KT == 3 ? iqs : LS;
     const uint8_t* qb[NH];  // (the cursor's tile bases BEFORE it advances: the last slot of a round still belongs to the old tile)
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) qb[hf] = cb[hf];
@@ -478,19 +535,19 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[t][r] = 0;
       }
-      uint32_t alo[3], ahi[3];
+      uint32_t alo[ROWS], ahi[ROWS];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < ROWS; ++r) {
         alo[r] = fa + sb + (uint32_t)(r * a.PWp);
         ahi[r] = alo[r] + pitch8;
       }
       if constexpr (!STAT) {
         const uint32_t wab = wa + sb;
         asm volatile("ds_read_b128 %0, %1" : "=v"(wr[0]) : "v"(wab) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(wr[1]) : "v"(wab) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wr[2]) : "v"(wab) : "memory");
+        if constexpr (ROWS >= 2) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(wr[1]) : "v"(wab) : "memory");
+        if constexpr (ROWS == 3) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wr[2]) : "v"(wab) : "memory");
       }
-      constexpr int NM = 3 * NTW;  // MFMA i <-> (tap row i / NTW, n tile i % NTW)
+      constexpr int NM = ROWS * NTW;  // MFMA i <-> (tap row i / NTW, n tile i % NTW)
 #define PLHIP_PATCH_READ(I_)                                                                                              \
   do {                                                                                                                    \
     constexpr int r_ = (I_) / NTW, t_ = (I_) % NTW, f_ = (I_) & 3;                                                        \
@@ -500,7 +557,10 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
       PLHIP_PATCH_READ(0);
       PLHIP_PATCH_READ(1);
       PLHIP_PATCH_READ(2);
-      if constexpr (!STAT) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2])::"memory");
+      if constexpr (!STAT && ROWS == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2])::"memory");
+      if constexpr (!STAT && ROWS == 2) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wr[0]), "+v"(wr[1])::"memory");
+      if constexpr (!STAT && ROWS == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wr[0])::"memory");
+      constexpr int IEV = NM >= 4 * NPI - 2 ? 4 : 2;  // a DMA piece behind every IEV-th MFMA
       patch_static_for<0, NM>([&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
         constexpr int r = i / NTW, t = i % NTW, f = i & 3;
@@ -519,11 +579,11 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i + 3 < NM) PLHIP_PATCH_READ(i + 3);
-        if constexpr (i % 4 == 1 && i / 4 < NPW) issue_piece(integral_constant<int, i / 4>{}, qb, qc, qs, islot);
+        if constexpr (i % IEV == 1 && i / IEV < NPI) issue_piece(integral_constant<int, i / IEV>{}, qb, qc, qs, islot);
         __builtin_amdgcn_sched_barrier(0);
       });
 #undef PLHIP_PATCH_READ
-      static_assert(4 * (NPW - 1) + 1 < NM, "every piece has its MFMA");
+      static_assert(IEV * (NPI - 1) + 1 < NM, "every piece has its MFMA");
     }
     if (diag && nstep < 6 && lane == 0) lstamp[11 + nstep] = __builtin_amdgcn_s_memtime();
     ++nstep;
@@ -538,7 +598,7 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   cursor_tiles(0);
   patch_static_for<0, D>([&](auto p_c) __attribute__((always_inline)) {
     constexpr int pp = decltype(p_c)::value;
-    issue(iqc, iqs, pp);
+    issue(iqc, std::integral_constant<int, pp % SPG>{}, pp);
     advance_cursor();
     if constexpr (STAT) {
       load_w(std::integral_constant<int, 3 * pp>{});
@@ -569,7 +629,8 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
       step(I1{}, I2{}, I0{}, r0, false);
     } else {
       if (k == 0 && OUT != OUT_I32) {  // scale / bias: older than every DMA piece, so long landed at the first epilogue
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NPW) : "memory");
+        constexpr int NPRO = patch_npws_sum<KT, NPW>(0, D);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPRO) : "memory");
         asm volatile("" : "+v"(sc), "+v"(bi));
       }
       for (int ic = 0; ic < NCH; ++ic) {
@@ -577,6 +638,11 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
         step(IR{}, integral_constant<int, 0>{}, integral_constant<int, 2>{}, false, ic == 0);
         step(IR{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, false, false);
         step(IR{}, integral_constant<int, 2>{}, integral_constant<int, 0>{}, false, false);
+        if constexpr (KT == 2) {
+          step(IR{}, integral_constant<int, 3>{}, integral_constant<int, 0>{}, false, false);
+          step(IR{}, integral_constant<int, 4>{}, integral_constant<int, 0>{}, false, false);
+          step(IR{}, integral_constant<int, 5>{}, integral_constant<int, 0>{}, false, false);
+        }
       }
     }
     if (live && !(a.dbg & 1)) {  // (PLHIP_PATCH_DEBUG & 1: no epilogue; timing experiments)
@@ -606,27 +672,27 @@ __global__ __launch_bounds__(256 * NH, 2) void conv_patch_i8_kernel(PatchArgs a)
   }
 }
 
-template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT>
+template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT, int OUT, int KT = 3>
 static inline void launch_patch_t(const PatchArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)NSLOT * (NH * 32 * a.pitch + (STAT ? 0 : 3 * WMH * 1024));
+  const size_t lds = (size_t)NSLOT * (NH * 32 * a.pitch + (STAT ? 0 : KT * WMH * 1024));
   const unsigned blocks = (unsigned)(8 * a.MB * a.NQ);
   const bool nonneg = a.act == ACT_RELU || a.act == ACT_RELU6;
   if (OUT == OUT_I8 && !nonneg) {
-    auto kfn = conv_patch_i8_kernel<NH, WMH, WNH, NPW, NSLOT, STAT, OUT, false>;
+    auto kfn = conv_patch_i8_kernel<NH, WMH, WNH, NPW, NSLOT, STAT, OUT, false, KT>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256 * NH), lds, s, a);
   } else {
-    auto kfn = conv_patch_i8_kernel<NH, WMH, WNH, NPW, NSLOT, STAT, OUT, true>;
+    auto kfn = conv_patch_i8_kernel<NH, WMH, WNH, NPW, NSLOT, STAT, OUT, true, KT>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256 * NH), lds, s, a);
   }
 }
 
-template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT>
+template <int NH, int WMH, int WNH, int NPW, int NSLOT, bool STAT, int KT = 3>
 static inline void launch_patch_o(const PatchArgs& a, int out, hipStream_t s) {
-  if (out == OUT_I32) launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_I32>(a, s);
-  else if (out == OUT_F32) launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_F32>(a, s);
-  else launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_I8>(a, s);
+  if (out == OUT_I32) launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_I32, KT>(a, s);
+  else if (out == OUT_F32) launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_F32, KT>(a, s);
+  else launch_patch_t<NH, WMH, WNH, NPW, NSLOT, STAT, OUT_I8, KT>(a, s);
 }
 
 }  // namespace plhip

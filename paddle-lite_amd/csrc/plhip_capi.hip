@@ -44,7 +44,7 @@ plhip_status fail(plhip_ctx* c, plhip_status st, const char* fmt, const char* a 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
-enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2, IMPL_IMPLICIT_GEMM = 3, IMPL_PATCH_GEMM = 4 };
+enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2, IMPL_IMPLICIT_GEMM = 3, IMPL_PATCH_GEMM = 4, IMPL_PATCH_S2 = 5 };
 
 struct ConvGeom {
   int oh, ow, G, Mg, Cg, Kg, N, Np, MA, MT, MT32, KS;
@@ -77,6 +77,17 @@ static void padded_dims(const plhip_conv_desc* d, int* ph, int* pw) {
 static size_t patch_input_bytes(const plhip_conv_desc* d) {
   const int pwp = plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3]);
   const size_t b = (size_t)d->n * d->cin * (d->h + d->pad[0] + d->pad[1]) * pwp;
+  return ((b + 15) & ~(size_t)15) + 4096;
+}
+// the phase-split copy of the stride-2 patch route: 4 phase planes per channel, rows of PW2p (a multiple of 8) bytes
+static void patch_s2_dims(const plhip_conv_desc* d, int* ph2, int* pw2p) {
+  *pw2p = plhip::conv_patch_s2_row_pitch(d->w, d->pad[2], d->pad[3]);
+  *ph2 = (d->h + d->pad[0] + d->pad[1] + 1) >> 1;
+}
+static size_t patch_s2_input_bytes(const plhip_conv_desc* d) {
+  int ph2, pw2p;
+  patch_s2_dims(d, &ph2, &pw2p);
+  const size_t b = (size_t)d->n * d->cin * 4 * ph2 * pw2p;
   return ((b + 15) & ~(size_t)15) + 4096;
 }
 static size_t padded_input_bytes(const plhip_conv_desc* d) {  // + slack: the last 16-byte pieces run past the last row
@@ -132,6 +143,16 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
       // (global mode, planes smaller than a tile: a 16-byte output piece may end in the NEXT image, not beyond it)
       !(plhip::conv_patch_global(plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3])) && g->oh * g->ow < 16)) {
     g->impl = IMPL_PATCH_GEMM;
+    return true;
+  }
+  // dense 3x3 stride 2 (ResNet50's downsampling convs): the same kernel as a 2x2 stride-1 conv over the 4 phase planes of
+  // every channel (conv_patch_i8.hip)
+  if (g->impl == IMPL_IM2COL_GEMM &&
+      plhip::conv_patch_s2_supported(d->cin, d->cout, d->kh, d->kw, d->stride[0], d->stride[1], d->dil[0], d->dil[1], d->groups,
+                                     d->w, d->pad[2], d->pad[3]) &&
+      patch_s2_input_bytes(d) < ((size_t)1 << 31) - 4096 &&
+      !(plhip::conv_patch_global(plhip::conv_patch_s2_row_pitch(d->w, d->pad[2], d->pad[3])) && g->oh * g->ow < 16)) {
+    g->impl = IMPL_PATCH_S2;
     return true;
   }
   if (g->impl == IMPL_IM2COL_GEMM && d->groups == 1 && (s1 || s2) && d->dil[0] == 1 && d->dil[1] == 1 && d->kw <= 11 &&
@@ -299,6 +320,7 @@ size_t plhip_conv_packed_weight_bytes(const plhip_conv_desc* d) {
   if (!conv_geom(d, &g)) return 0;
   if (g.impl == IMPL_DIRECT_3X3S2) return plhip::conv3x3s2_direct_packed_bytes(d->cin, d->cout);
   if (g.impl == IMPL_PATCH_GEMM) return plhip::conv_patch_packed_bytes(d->cin, d->cout);
+  if (g.impl == IMPL_PATCH_S2) return plhip::conv_patch_s2_packed_bytes(d->cin, d->cout);
   return (size_t)g.G * g.MT32 * g.KS * 1024;
 }
 
@@ -311,6 +333,8 @@ plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d, c
     plhip::launch_pack_conv3x3s2_direct(w_oihw, (uint32_t*)w_packed, d->cin, d->cout, ctx->stream);
   } else if (g.impl == IMPL_PATCH_GEMM) {
     plhip::launch_pack_conv_patch(w_oihw, (int8_t*)w_packed, d->cin, d->cout, ctx->stream);
+  } else if (g.impl == IMPL_PATCH_S2) {
+    plhip::launch_pack_conv_patch_s2(w_oihw, (int8_t*)w_packed, d->cin, d->cout, ctx->stream);
   } else {
     plhip::launch_pack_weights(w_oihw, (int8_t*)w_packed, g.G, g.Mg, g.Kg, g.MT32, g.KS, ctx->stream);
   }
@@ -323,6 +347,7 @@ size_t plhip_conv_workspace_bytes(const plhip_conv_desc* d) {
   if (!conv_geom(d, &g)) return 0;
   if (g.impl == IMPL_IMPLICIT_GEMM) return padded_input_bytes(d);
   if (g.impl == IMPL_PATCH_GEMM) return patch_input_bytes(d);
+  if (g.impl == IMPL_PATCH_S2) return patch_s2_input_bytes(d);
   if (g.impl != IMPL_IM2COL_GEMM) return 0;
   return (size_t)d->n * g.G * g.Kg * g.Np;
 }
@@ -335,6 +360,7 @@ const char* plhip_conv_impl_name(const plhip_conv_desc* d) {
     return (d->cin * 3 <= 9 && (g.ow & 3) == 0) ? "conv_3x3s2_direct_int8_mfma32x32x32" : "conv_3x3s2_direct_int8_dot4";
   if (g.impl == IMPL_IMPLICIT_GEMM) return "conv_implicit_gemm_int8_mfma32x32x32";
   if (g.impl == IMPL_PATCH_GEMM) return "conv_patch_gemm_int8_mfma32x32x32";
+  if (g.impl == IMPL_PATCH_S2) return "conv_patch_s2_gemm_int8_mfma32x32x32";
   return "conv_im2col_gemm_int8_mfma32x32x32";
 }
 
@@ -380,21 +406,25 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     LAUNCHCHK(ctx, "conv3x3s2_direct");
     return PLHIP_OK;
   }
-  if (g.impl == IMPL_PATCH_GEMM) {
-    const size_t need = patch_input_bytes(d);
+  if (g.impl == IMPL_PATCH_GEMM || g.impl == IMPL_PATCH_S2) {
+    const bool s2 = g.impl == IMPL_PATCH_S2;
+    const size_t need = s2 ? patch_s2_input_bytes(d) : patch_input_bytes(d);
     if (!workspace || workspace_bytes < need || !aligned(workspace, 16))
       return fail(ctx, PLHIP_ERR_WORKSPACE, "plhip_conv2d_int8: padded-input workspace missing, too small or unaligned (16 bytes)");
-    const int PWp = plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3]), PH = d->h + d->pad[0] + d->pad[1];
+    int PWp = plhip::conv_patch_row_pitch(d->w, d->pad[2], d->pad[3]), PH = d->h + d->pad[0] + d->pad[1];
+    if (s2) patch_s2_dims(d, &PH, &PWp);
+    const int CE = s2 ? 4 * d->cin : d->cin;  // the kernel's channels: stride 2 = (channel, row phase, column phase)
     plhip::PadArgs pa;
-    pa.stride = 1;
+    pa.stride = d->stride[0];
     pa.x = x;
     pa.xp = (int8_t*)workspace;
-    pa.planes = d->n * d->cin;
+    pa.planes = d->n * CE;
     pa.h = d->h; pa.w = d->w; pa.ph = PH; pa.pw = PWp; pa.pt = d->pad[0]; pa.pl = d->pad[2];
     pa.total = (long)need;
     pa.tb = plhip::conv_patch_global(PWp) ? d->n : 0;  // planes smaller than a tile: channel-major copy
-    pa.tc = d->cin;
-    plhip::launch_pad_rows8(pa, ctx->stream);
+    pa.tc = CE;
+    if (s2) plhip::launch_pad_phase8(pa, ctx->stream);
+    else plhip::launch_pad_rows8(pa, ctx->stream);
     LAUNCHCHK(ctx, "pad_rows8");
     plhip::PatchArgs a;
     memset(&a, 0, sizeof(a));
@@ -403,9 +433,10 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     a.y = y;
     a.scale = scale;
     a.bias = bias;
-    a.B = d->n; a.C = d->cin; a.M = d->cout; a.OH = g.oh; a.OW = g.ow;
+    a.B = d->n; a.C = CE; a.M = d->cout; a.OH = g.oh; a.OW = g.ow;
     a.PWp = PWp;
     a.PLANE = PH * PWp;
+    a.s2 = s2 ? 1 : 0;
     a.act = d->act;
     a.alpha = d->act_alpha;
     a.res = t_res; a.res_relu = t_relu; a.y2 = t_y2; a.inv_scale2 = t_inv;

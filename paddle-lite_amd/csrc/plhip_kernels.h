@@ -86,6 +86,7 @@ struct PatchArgs {
   float inv_scale2;
   int dbg;
   // global mode (planes smaller than a tile: 7-wide): the padded copy is [c][image][PH][PWp], p runs over all images
+  int s2;              // 3x3 stride 2 as a 2x2 conv over phase planes: C = 4 Cin, the slabs are walked with 2 taps per side
   int glob, nimg, IMGP;  // nimg = the real image count; IMGP = PH * PWp pixels per image (PLANE is then the CHANNEL stride B * IMGP, B = 1, TPI = T)
   unsigned imgp_m, hwy_m;
   int imgp_s, hwy_s;
@@ -103,6 +104,12 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s);
 void launch_patch_stat_a(const PatchArgs& a, int out, hipStream_t s);    // per-variant translation units
 void launch_patch_stat_b(const PatchArgs& a, int out, hipStream_t s);
 void launch_patch_stream_a(const PatchArgs& a, int out, hipStream_t s);
+void launch_patch_s2(const PatchArgs& a, int out, hipStream_t s);
+int conv_patch_s2_row_pitch(int w, int pl, int pr);
+bool conv_patch_s2_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int w, int pl, int pr);
+size_t conv_patch_s2_packed_bytes(int cin, int cout);
+void launch_pack_conv_patch_s2(const int8_t* w_oihw, int8_t* wp, int cin, int cout, hipStream_t s);
+void launch_pad_phase8(PadArgs a, hipStream_t s);
 int debug_read_patch_stamps(void* dst, size_t bytes);
 
 struct Im2colArgs {

@@ -303,7 +303,7 @@ def test_implicit_gemm_stride2_phase_split(gpu_ctx, plref, pkg):
         (3, 16, 48, 15, 17, 3, (1, 1, 1, 1)),      # odd extents
         (2, 16, 40, 14, 14, 3, (0, 1, 0, 1)),      # asymmetric pads, 7-column output rows
         (1, 8, 96, 33, 31, 5, (2, 2, 2, 2)),
-        (2, 128, 128, 56, 56, 3, (1, 1, 1, 1)),    # res3a_branch2b itself
+        (2, 128, 128, 56, 56, 3, (1, 1, 1, 1)),    # res3a_branch2b itself: Cin % 32 == 0 and M > 64, the patch kernel's stride-2 form
     ]
     for (n, cin, cout, h, wd, k, pads) in cases:
         x = rng.integers(-127, 128, (n, cin, h, wd)).astype(np.int8)
@@ -311,7 +311,8 @@ def test_implicit_gemm_stride2_phase_split(gpu_ctx, plref, pkg):
         bias = rng.uniform(-1, 1, cout).astype(np.float32)
         wsc = ((1 + np.arange(cout) % 5) / 127.0 / 4.0).astype(np.float32)
         d = capi.conv_desc(n, cin, h, wd, cout, k, k, pads, (2, 2), (1, 1), 1, capi.ACT_RELU, 0.0)
-        assert capi.load().plhip_conv_impl_name(d).decode().startswith("conv_implicit_gemm"), (cin, cout, h, k)
+        want = "conv_patch_s2_gemm" if (k == 3 and cin % 32 == 0 and cout > 64) else "conv_implicit_gemm"
+        assert capi.load().plhip_conv_impl_name(d).decode().startswith(want), (cin, cout, h, k)
         s = plref.shape(n, cin, h, wd, cout, k, k, pads, (2, 2), (1, 1), 1)
         acc_ref = plref.conv2d_acc(s, x, w)
         assert np.array_equal(gpu_ctx.conv2d(d, x, w, None, None, capi.OUT_I32), acc_ref), (cin, cout, h, k)

@@ -361,6 +361,24 @@ def test_patch_conv_route(gpu_ctx, pkg, plref):
                                 act != 4, rng) == 1, (n, cin, h, w, cout, pads, act)
 
 
+def test_patch_conv_stride2_route(gpu_ctx, pkg, plref):
+    """Dense 3x3 stride-2 convs with Cin % 32 == 0 and M > 64 on the patch kernel over phase planes (ResNet50's downsampling
+    convs): even / odd extents, asymmetric and zero pads, M blocks and tails, more tiles than tile streams, planes smaller
+    than a tile (global mode: channel-major phase copy), every activation and output kind."""
+    rng = np.random.default_rng(137)
+    capi = pkg.capi
+    cases = [  # n, cin, h, w, cout, pads(t,b,l,r), act
+        (2, 128, 56, 56, 128, (1, 1, 1, 1), 1), (2, 256, 28, 28, 256, (1, 1, 1, 1), 1), (3, 512, 14, 14, 512, (1, 1, 1, 1), 1),
+        (2, 64, 20, 21, 96, (1, 0, 1, 0), 2), (1, 32, 33, 40, 130, (0, 1, 0, 1), 4), (530, 64, 12, 28, 96, (1, 1, 1, 1), 1),
+        (9, 64, 14, 14, 65, (1, 1, 1, 1), 2), (1, 64, 13, 13, 96, (1, 1, 1, 1), 0), (5, 96, 9, 11, 72, (0, 0, 0, 0), 0),
+        (2, 32, 57, 120, 70, (1, 1, 1, 1), 1)]
+    for (n, cin, h, w, cout, pads, act) in cases:
+        d = capi.conv_desc(n, cin, h, w, cout, 3, 3, pads, (2, 2), (1, 1), 1, act, 0.0)
+        assert gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) == b"conv_patch_s2_gemm_int8_mfma32x32x32", (cin, cout, w, pads)
+        assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 3, 3, pads, 2, 1, 1, act, 6.0 if act == 2 else 0.25,
+                                act != 4, rng) == 1, (n, cin, h, w, cout, pads, act)
+
+
 def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
     capi = pkg.capi
     g = load_golden(golden_files("fc_")[0])

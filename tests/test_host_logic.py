@@ -47,10 +47,18 @@ def test_descriptor_helpers(pkg):
     d48 = capi.conv_desc(32, 48, 56, 56, 128, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1)
     assert lib.plhip_conv_workspace_bytes(ctypes.byref(d48)) == 32 * 48 * 58 * 58 + 64
     assert lib.plhip_conv_impl_name(ctypes.byref(d48)) == b"conv_implicit_gemm_int8_mfma32x32x32"
-    # stride 2: implicit GEMM on the PHASE-SPLIT padded copy: 4 planes of ceil(58/2) x roundup(ceil(58/2), 4) per channel
+    # 3x3 stride 2, Cin % 32 == 0, M > 64: the patch kernel over the PHASE-SPLIT padded copy: 4 planes of ceil(58/2) rows of
+    # roundup(ceil(58/2), 8) bytes per channel + slack; the packed weights: 9 fragments per (m tile, 32 channels)
     s2 = capi.conv_desc(32, 64, 56, 56, 128, 3, 3, (1, 1, 1, 1), (2, 2), (1, 1), 1)
-    assert lib.plhip_conv_workspace_bytes(ctypes.byref(s2)) == 32 * 64 * 4 * 29 * 32 + 64
-    assert lib.plhip_conv_impl_name(ctypes.byref(s2)) == b"conv_implicit_gemm_int8_mfma32x32x32"
+    assert lib.plhip_conv_workspace_bytes(ctypes.byref(s2)) == 32 * 64 * 4 * 29 * 32 + 4096
+    assert lib.plhip_conv_packed_weight_bytes(ctypes.byref(s2)) == 4 * 2 * 9 * 1024
+    assert lib.plhip_conv_impl_name(ctypes.byref(s2)) == b"conv_patch_s2_gemm_int8_mfma32x32x32"
+    # ... with a channel tail or M <= 64: the ring kernel's implicit GEMM on its own phase-split copy (rows rounded up to 4)
+    s2b = capi.conv_desc(32, 48, 56, 56, 128, 3, 3, (1, 1, 1, 1), (2, 2), (1, 1), 1)
+    assert lib.plhip_conv_workspace_bytes(ctypes.byref(s2b)) == 32 * 48 * 4 * 29 * 32 + 64
+    assert lib.plhip_conv_impl_name(ctypes.byref(s2b)) == b"conv_implicit_gemm_int8_mfma32x32x32"
+    s2c = capi.conv_desc(32, 64, 56, 56, 64, 3, 3, (1, 1, 1, 1), (2, 2), (1, 1), 1)
+    assert lib.plhip_conv_impl_name(ctypes.byref(s2c)) == b"conv_implicit_gemm_int8_mfma32x32x32"
     dil = capi.conv_desc(32, 64, 56, 56, 128, 3, 3, (2, 2, 2, 2), (1, 1), (2, 2), 1)  # dilation stays on im2col + GEMM
     assert lib.plhip_conv_workspace_bytes(ctypes.byref(dil)) == 32 * 576 * 3136
     assert lib.plhip_conv_impl_name(ctypes.byref(dil)) == b"conv_im2col_gemm_int8_mfma32x32x32"

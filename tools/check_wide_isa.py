@@ -24,7 +24,7 @@ CSRC = os.path.join(ROOT, "paddle-lite_amd", "csrc")
 REG = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
 VM_OPS = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "flat_load", "flat_store", "scratch_")
 KERN = re.compile(r"^(_ZN5plhip19gemm_i8_wide_kernelI\w+EvNS_8GemmArgsE|_ZN5plhip20conv_patch_i8_kernelI\w+EvNS_9PatchArgsE):")
-UNITS = ("gemm_wide_n4", "gemm_wide_n7", "gemm_wide_n8", "conv_patch_i8", "conv_patch_stat_b", "conv_patch_stream")
+UNITS = ("gemm_wide_n4", "gemm_wide_n7", "gemm_wide_n8", "conv_patch_i8", "conv_patch_stat_b", "conv_patch_stream", "conv_patch_s2")
 
 
 def regs(tok):
