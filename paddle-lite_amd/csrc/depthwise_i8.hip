@@ -14,6 +14,9 @@
 //   * results leave as one dword (4 x int8) or one 16-B vector (fp32 / int32) per lane, coalesced along W.
 // Fast paths: 3x3 and 5x5, stride 1 and 2, dilation 1, any padding.  Everything else (other k, dilation)
 // takes a scalar LDS-byte path in the same kernel.
+// 3x3 and 5x5 with stride 1 / 2, dilation 1 and left padding <= 3 do not go through LDS at all: the direct strip kernels
+// below (depthwise3x3_direct_kernel / depthwise5x5_direct_kernel: a lane = 4 outputs x RS rows, the input rows fetched
+// straight into registers, windows cut by v_alignbyte, v_dot4 per filter row + one more dot4 for a 5x5 row's fifth tap).
 #include <stdlib.h>
 
 #include "plhip_device.h"
@@ -258,17 +261,18 @@ __device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int r
 // instruction there carries 16 row segments of <= 14 bytes, 4.4 B per request.  With 64 % owq == 0 and RS | OH the 64 lanes
 // of a wave own one CONTIGUOUS output region ((64/owq) strips x RS rows x OW bytes); the results are assembled in LDS
 // and leave as contiguous dwords (256 B per store instruction).
-template <int OUT, int S, int RS, bool STAGE>
-__device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&in)[(RS - 1) * S + 3][S == 1 ? 2 : 3], long plane,
+// KS = 3 or 5 (square filter): the window of 4 outputs is 3 S + KS bytes = 2 dwords at stride 1, 3 at stride 2 for both.
+template <int OUT, int S, int RS, bool STAGE, int KS>
+__device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&in)[(RS - 1) * S + KS][S == 1 ? 2 : 3], long plane,
                                              int ch, int oy0, int xq, bool live, long gid_in, uint8_t* wlds);
 
-template <int OUT, int S, int RS, bool TAIL, bool STAGE>
+template <int OUT, int S, int RS, bool TAIL, bool STAGE, int KS>
 __device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, bool live, uint8_t* wlds) {
   // a dead lane (staging: the surplus lanes of a wave, the lanes past the end) recomputes its wave's FIRST quad: a live
   // one by the kernel's wave-level exit test, and inside whatever part of the tensor this workgroup's fetch variant is safe for
   const long gid = live ? gid_in : gid_in - (threadIdx.x & 63);
-  constexpr int NIN = (RS - 1) * S + 3;  // input rows per strip
-  constexpr int ND = S == 1 ? 2 : 3;     // dwords per row load
+  constexpr int NIN = (RS - 1) * S + KS;  // input rows per strip
+  constexpr int ND = S == 1 ? 2 : 3;      // dwords per row load
   const int owq = (a.ow + 3) >> 2;
   const int spp = (a.oh + RS - 1) / RS;  // strips per plane
   // gid -> (plane, strip, quad); shifts when the divisors are powers of two (the common case), wave-uniform choice
@@ -317,20 +321,31 @@ __device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, 
 #pragma unroll
   for (int t = 0; t < NIN; ++t) dw_load_row<ND, TAIL>(xplane, iy0 + t, a.h, a.w, lcol, sh, plane_room, cmask, in[t]);
 
-  dw3x3_finish<OUT, S, RS, STAGE>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
+  dw3x3_finish<OUT, S, RS, STAGE, KS>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
 }
 
 // Second half of a strip, shared by the general and the fast row fetch: filter / scale fetch, the dot4 accumulation
 // over the NIN input rows in registers, requantisation and the store (direct, or staged through LDS).
-template <int OUT, int S, int RS, bool STAGE>
-__device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&in)[(RS - 1) * S + 3][S == 1 ? 2 : 3], long plane,
+template <int OUT, int S, int RS, bool STAGE, int KS>
+__device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&in)[(RS - 1) * S + KS][S == 1 ? 2 : 3], long plane,
                                              int ch, int oy0, int xq, bool live, long gid_in, uint8_t* wlds) {
-  constexpr int NIN = (RS - 1) * S + 3;
+  constexpr int NIN = (RS - 1) * S + KS;
   constexpr int ND = S == 1 ? 2 : 3;
   // filter rows packed (w0, w1, w2, 0): three unaligned dword loads; the last one is taken one byte early and shifted so
-  // that it never reads past the end of the filter tensor
-  uint32_t wr[3];
-  {
+  // that it never reads past the end of the filter tensor.  5x5: (w0 .. w3) and (w4, 0, 0, 0) per row, the fifth tap from the
+  // top byte of the dword one byte further on (in bounds for the last row of the last channel too)
+  uint32_t wr[KS], wr4[KS];
+  if constexpr (KS == 5) {
+    const int8_t* wp = a.wt + (size_t)ch * 25;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      uint32_t lo, hi;
+      __builtin_memcpy(&lo, wp + 5 * r, 4);
+      __builtin_memcpy(&hi, wp + 5 * r + 1, 4);
+      wr[r] = lo;
+      wr4[r] = hi >> 24;
+    }
+  } else {
     const int8_t* wp = a.wt + (size_t)ch * 9;
     uint32_t w0, w1, w2;
     __builtin_memcpy(&w0, wp, 4);
@@ -359,14 +374,30 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
       win[2] = in[t][1];
       win[3] = __builtin_amdgcn_alignbyte(in[t][ND - 1], in[t][1], 2);
     }
+    uint32_t win4[4];  // 5x5: a dword whose byte 0 is the fifth tap's column (byte S j + 4 of the window) of output j
+    if constexpr (KS == 5) {
+      if (S == 1) {
+        win4[0] = in[t][1];
+        win4[1] = in[t][1] >> 8;
+        win4[2] = in[t][1] >> 16;
+        win4[3] = in[t][1] >> 24;
+      } else {
+        win4[0] = in[t][1];
+        win4[1] = in[t][1] >> 16;
+        win4[2] = in[t][ND - 1];
+        win4[3] = in[t][ND - 1] >> 16;
+      }
+    }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < KS; ++r) {
       if ((t - r) % S != 0) continue;
       const int o = (t - r) / S;
       if (t - r < 0 || o >= RS) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
         acc[o][j] = r == 0 ? sdot4_first(win[j], wr[0]) : __builtin_amdgcn_sdot4((int)win[j], (int)wr[r], acc[o][j], false);
+        if constexpr (KS == 5) acc[o][j] = __builtin_amdgcn_sdot4((int)win4[j], (int)wr4[r], acc[o][j], false);
+      }
     }
   }
 
@@ -461,12 +492,13 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
 // left: one 32-bit offset add, one load and ND ANDs per row.  (PMC: the general fetch spent ~14 VALU per row and the
 // large layers ran at 94 % VALU issue -- this op is VALU-bound before it is HBM-bound.)  The first workgroup (a window
 // may start before the tensor) and the last ones (it may end after it) use the guarded general body instead.
-template <int OUT, int S, int RS, bool STAGE>
+template <int OUT, int S, int RS, bool STAGE, int KS>
 __device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, bool live, uint8_t* wlds) {
   // a dead lane (staging: the surplus lanes of a wave, the lanes past the end) recomputes its wave's FIRST quad: a live
   // one by the kernel's wave-level exit test, and inside whatever part of the tensor this workgroup's fetch variant is safe for
   const long gid = live ? gid_in : gid_in - (threadIdx.x & 63);
-  constexpr int NIN = (RS - 1) * S + 3;
+  constexpr int NIN = (RS - 1) * S + KS;
+  constexpr int PV = (KS - 1) / 2;  // rows at either end of a strip that may lie outside the image (vertical padding <= PV)
   constexpr int ND = S == 1 ? 2 : 3;
   const int owq = (a.ow + 3) >> 2;
   const int spp = a.oh / RS;
@@ -492,15 +524,16 @@ __device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, bo
   const int start = 4 * xq * S - a.pl;
   uint32_t cmask[ND];
   dw_col_masks<ND>(start, a.w, cmask);
-  // rows 1 .. NIN-2 are always inside the image
-  const uint32_t off1 = (uint32_t)((int)plane * a.h * a.w + (iy0 + 1) * a.w + start);
-  const bool top_ok = iy0 >= 0, bot_ok = iy0 + NIN - 1 < a.h;
+  // rows PV .. NIN-1-PV are always inside the image; an outside row fetches row PV again (a legal address) under a zero mask
+  const uint32_t offp = (uint32_t)((int)plane * a.h * a.w + (iy0 + PV) * a.w + start);
   uint32_t in[NIN][ND];
+  bool ok[NIN];
 #pragma unroll
   for (int t = 0; t < NIN; ++t) {
-    uint32_t off = off1 + (uint32_t)((t - 1) * a.w);
-    if (t == 0) off = top_ok ? off : off1;
-    if (t == NIN - 1) off = bot_ok ? off : off1;
+    ok[t] = true;
+    if (t < PV) ok[t] = iy0 + t >= 0;
+    if (t >= NIN - PV) ok[t] = iy0 + t < a.h;
+    const uint32_t off = ok[t] ? offp + (uint32_t)((t - PV) * a.w) : offp;
     __builtin_memcpy(in[t], a.x + off, 4 * ND);
   }
 #pragma unroll
@@ -508,15 +541,14 @@ __device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, bo
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
       uint32_t m = cmask[d];
-      if (t == 0) m = top_ok ? m : 0u;
-      if (t == NIN - 1) m = bot_ok ? m : 0u;
+      if (t < PV || t >= NIN - PV) m = ok[t] ? m : 0u;
       in[t][d] &= m;
     }
-  dw3x3_finish<OUT, S, RS, STAGE>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
+  dw3x3_finish<OUT, S, RS, STAGE, KS>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
 }
 
-template <int OUT, int S, int RS, bool STAGE, bool FASTV>
-__global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
+template <int OUT, int S, int RS, bool STAGE, bool FASTV, int KS>
+__device__ __forceinline__ void dw_direct_kernel_body(DwArgs a) {
   PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.wt); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias);
   PLHIP_PRELOAD(a.planes); PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.h); PLHIP_PRELOAD(a.w); PLHIP_PRELOAD(a.oh); PLHIP_PRELOAD(a.ow);
   PLHIP_PRELOAD(a.pt); PLHIP_PRELOAD(a.pl); PLHIP_PRELOAD(a.total_lanes); PLHIP_PRELOAD(a.owq_log2); PLHIP_PRELOAD(a.spp_log2);
@@ -540,12 +572,21 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
   const bool live = STAGE ? (lane_w < a.lw && gid < a.total_lanes) : true;
   uint8_t* wlds = STAGE ? dw_stage + (threadIdx.x >> 6) * a.stage_bytes : nullptr;
   // only the last workgroups can touch the final bytes of the tensor: they alone pay for the guarded loads
-  if (vb + 4 >= nb) dw3x3_direct_body<OUT, S, RS, true, STAGE>(a, gid, live, wlds);
-  else if (FASTV && vb != 0) dw3x3_fast_body<OUT, S, RS, STAGE>(a, gid, live, wlds);
-  else dw3x3_direct_body<OUT, S, RS, false, STAGE>(a, gid, live, wlds);
+  if (vb + 4 >= nb) dw3x3_direct_body<OUT, S, RS, true, STAGE, KS>(a, gid, live, wlds);
+  else if (FASTV && vb != 0) dw3x3_fast_body<OUT, S, RS, STAGE, KS>(a, gid, live, wlds);
+  else dw3x3_direct_body<OUT, S, RS, false, STAGE, KS>(a, gid, live, wlds);
+}
+template <int OUT, int S, int RS, bool STAGE, bool FASTV>
+__global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(DwArgs a) {
+  dw_direct_kernel_body<OUT, S, RS, STAGE, FASTV, 3>(a);
+}
+// the same strip kernel with 5 filter rows of (dot4, fifth tap) per output row (conv5x5s{1,2}_depthwise_int8.cc)
+template <int OUT, int S, int RS, bool STAGE, bool FASTV>
+__global__ __launch_bounds__(256) void depthwise5x5_direct_kernel(DwArgs a) {
+  dw_direct_kernel_body<OUT, S, RS, STAGE, FASTV, 5>(a);
 }
 
-template <int OUT, int S>
+template <int OUT, int S, int KS>
 static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
   const long owq = (a_in.ow + 3) >> 2;
   const long spp = (a_in.oh + rs - 1) / rs;
@@ -596,10 +637,14 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
     const char* e = getenv("PLHIP_DW_FASTV");
     fast_env = e ? atoi(e) : 1;
   }
-  const bool fastv = fast_env && a.pt <= 1 && (a.oh - 1) * S + 2 - a.pt <= a.h && a.oh % rs == 0 &&
+  constexpr int PV = (KS - 1) / 2;
+  const bool fastv = fast_env && a.pt <= PV && (a.oh - 1) * S + KS - 1 - a.pt <= a.h - 1 + PV && a.oh % rs == 0 &&
                      (owq - 1) * 4 * S - a.pl < a.w;
-#define PLHIP_DW_LAUNCH(RSV, ST, FV) \
-  hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, RSV, ST, FV>), dim3(blocks), dim3(256), lds, s, a)
+#define PLHIP_DW_LAUNCH(RSV, ST, FV)                                                                               \
+  do {                                                                                                             \
+    if (KS == 5) hipLaunchKernelGGL((depthwise5x5_direct_kernel<OUT, S, RSV, ST, FV>), dim3(blocks), dim3(256), lds, s, a); \
+    else hipLaunchKernelGGL((depthwise3x3_direct_kernel<OUT, S, RSV, ST, FV>), dim3(blocks), dim3(256), lds, s, a);         \
+  } while (0)
 #define PLHIP_DW_RS(ST, FV)              \
   do {                                   \
     if (rs == 8) PLHIP_DW_LAUNCH(8, ST, FV);      \
@@ -615,7 +660,13 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
 }
 
 static bool launch_dw_direct(const DwArgs& a, int out, hipStream_t s) {
-  if (!(a.kh == 3 && a.kw == 3 && a.dh == 1 && a.dw == 1 && a.sh == a.sw && (a.sw == 1 || a.sw == 2) && a.pl <= 3)) return false;
+  static int k5_env = -1;
+  if (k5_env < 0) {
+    const char* e = getenv("PLHIP_DW5_DIRECT");  // 0 = 5x5 filters on the LDS-band kernel (A/B runs)
+    k5_env = e ? atoi(e) : 1;
+  }
+  const bool k3 = a.kh == 3 && a.kw == 3, k5 = a.kh == 5 && a.kw == 5 && k5_env;
+  if (!((k3 || k5) && a.dh == 1 && a.dw == 1 && a.sh == a.sw && (a.sw == 1 || a.sw == 2) && a.pl <= 3)) return false;
   if ((long)a.planes * a.h * a.w >= (1L << 31) || (long)a.planes * a.oh * a.ow >= (1L << 31)) return false;
   // rows per strip: amortise the 2-row halo while keeping many lanes (and bytes) in flight
   int rs;
@@ -637,9 +688,15 @@ static bool launch_dw_direct(const DwArgs& a, int out, hipStream_t s) {
     else rs = (a.oh % 7 == 0 && a.oh <= 14) ? 7 : 4;  // taller strips measured slower (dw3 33.7 -> 37.1 us): not VALU-bound
   }
   const bool s1 = a.sw == 1;
-  if (out == OUT_I32) s1 ? launch_dw_direct_s<OUT_I32, 1>(a, rs, s) : launch_dw_direct_s<OUT_I32, 2>(a, rs, s);
-  else if (out == OUT_F32) s1 ? launch_dw_direct_s<OUT_F32, 1>(a, rs, s) : launch_dw_direct_s<OUT_F32, 2>(a, rs, s);
-  else s1 ? launch_dw_direct_s<OUT_I8, 1>(a, rs, s) : launch_dw_direct_s<OUT_I8, 2>(a, rs, s);
+#define PLHIP_DW_OUT(O)                                                                              \
+  do {                                                                                               \
+    if (k5) s1 ? launch_dw_direct_s<O, 1, 5>(a, rs, s) : launch_dw_direct_s<O, 2, 5>(a, rs, s);      \
+    else s1 ? launch_dw_direct_s<O, 1, 3>(a, rs, s) : launch_dw_direct_s<O, 2, 3>(a, rs, s);         \
+  } while (0)
+  if (out == OUT_I32) PLHIP_DW_OUT(OUT_I32);
+  else if (out == OUT_F32) PLHIP_DW_OUT(OUT_F32);
+  else PLHIP_DW_OUT(OUT_I8);
+#undef PLHIP_DW_OUT
   return true;
 }
 

@@ -282,6 +282,22 @@ def test_dw_fast_fetch_and_staging(gpu_ctx, pkg, plref):
     assert cnt == 18
 
 
+def test_dw5x5_direct_fetch_and_staging(gpu_ctx, pkg, plref):
+    """depthwise 5x5 on the direct strip kernel (pad <= 3; conv5x5s{1,2}_depthwise_int8.cc shapes): fast row fetch (pad <= 2,
+    RS | OH: two rows at either end of a strip may leave the image) against the general fetch (pad 3, ragged OH), LDS output
+    staging for narrow planes, partial last waves, single-plane tensors, the fifth tap of the last channel's last filter row."""
+    rng = np.random.default_rng(139)
+    capi = pkg.capi
+    cnt = 0
+    for st in (1, 2):
+        for (c, h, w, pad) in [(5, 14, 14, 2), (37, 7, 7, 2), (3, 28, 28, 2), (1, 56, 56, 2), (9, 16, 12, 0), (4, 14, 14, 1),
+                               (130, 14, 14, 2), (2, 112, 112, 2), (6, 8, 30, 2), (3, 9, 9, 3), (1, 5, 5, 0), (64, 28, 28, 2)]:
+            act = (1, 2, 0, 4)[cnt % 4]
+            cnt += _check_all_kinds(gpu_ctx, capi, plref, 1 + cnt % 2, c, h, w, c, 5, 5, (pad,) * 4, st, 1, c, act,
+                                    6.0 if act == 2 else 0.3, cnt % 2 == 0, rng, depthwise=True)
+    assert cnt == 24
+
+
 def test_resnet50_and_mobilenetv2_layer_shapes(gpu_ctx, pkg, plref):
     """BASELINE configs C4 / C5 as parity cases (lite/tests/benchmark/src/convolution_configs.h:381-466, 839-891), batch 1-2:
     ResNet50: 7x7 s2 p3 stem, 3x3 s1 / s2 dense (im2col route), 1x1 stride-2 downsample, 1x1 with K = 2048;
