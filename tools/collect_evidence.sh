@@ -37,6 +37,8 @@ echo "sq done"
 cd $R
 python tools/pmc_sq.py $O/sq_c3 $O/pmc_sq_c3.csv > /dev/null || exit 1
 python tools/pmc_sq.py $O/sq_c4 $O/pmc_sq_c4.csv > /dev/null || exit 1
+# the stride-2 patch route: phase copy + kernel per downsampling layer
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/stats_s2 -o p --output-format csv -- python $R/tools/opbench.py s2 --net resnet50_3x3 --batch 256 > $O/opbench_s2_under_rocprof.txt 2> $O/stats_s2.err || exit 1
 fi
 if [ "$PART" = "1" ]; then exit 0; fi
 cd $R
@@ -52,10 +54,14 @@ PLHIP_GEMM_WIDE=0 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/gemm_timeli
 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3.txt || exit 1
 PLHIP_CONV_PATCH=0 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_patch_off.txt || exit 1
 PLHIP_PATCH_DEBUG=1 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_no_epilogue.txt || exit 1
+PLHIP_CONV_PATCH_S2=0 timeout -k 10 200 python tools/opbench.py s2 --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_s2_patch_off.txt || exit 1
 timeout -k 10 200 python tools/opbench.py all --net dw5x5 2>&1 | cut -c1-110 > $O/opbench_dw5x5.txt || exit 1
+PLHIP_DW5_DIRECT=0 timeout -k 10 200 python tools/opbench.py all --net dw5x5 2>&1 | cut -c1-110 > $O/opbench_dw5x5_lds_band.txt || exit 1
 PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py > $O/patch_timeline_c2.txt 2>&1 || exit 1
 ROUNDS=4 PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 64 --cout 64 --hw 56 > $O/patch_timeline_res2.txt 2>&1 || exit 1
 PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 256 --cout 256 --hw 14 > $O/patch_timeline_res4.txt 2>&1 || exit 1
+PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 128 --cout 128 --hw 56 --stride 2 > $O/patch_timeline_res3a_s2.txt 2>&1 || exit 1
+PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py --n 256 --cin 512 --cout 512 --hw 14 --stride 2 > $O/patch_timeline_res5a_s2.txt 2>&1 || exit 1
 echo "tables done"
 timeout -k 10 400 python bench.py --layer-table > $O/bench.json 2> $O/layer_table.txt || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_inflight1.json 2>/dev/null || exit 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-op micro-benchmark through the C ABI (device-resident buffers, HIP events on the ctx stream).
-Usage: python tools/opbench.py [pw|dw|conv1|all] [--batch 128] [--reps 30] [--net mobilenet_v1|dw5x5|resnet50_3x3]
+Usage: python tools/opbench.py [pw|dw|conv1|s2|all|<layer name>] [--batch 128] [--reps 30] [--net mobilenet_v1|dw5x5|resnet50_3x3]
 Prints one line per layer: time, algorithmic GB/s, TOP/s.  --net dw5x5: depthwise 5x5 stride 1 / 2 planes (the shapes of
 lite/tests/math/conv_int8_compute_test.cc's 5x5 depthwise sweep at network sizes); --net resnet50_3x3: BASELINE config #2
 (at its own batch 32) and ResNet50's dense 3x3 layers."""
@@ -63,7 +63,7 @@ def main():
             layers = wl.mobilenet_v1_layers()
         for (name, op, cin, cout, k, s, p, g, hin) in layers:
             kind = "conv1" if name == "conv1" else ("dw" if g > 1 else ("pw" if k == 1 else "conv"))
-            if args.what not in ("all", kind, name):
+            if args.what not in ("all", kind, name) and not (args.what == "s2" and kind == "conv" and s == 2):
                 continue
             B = 32 if name == "c2" else args.batch
             ho = (hin + 2 * p - k) // s + 1

@@ -23,13 +23,15 @@ def main():
     ap.add_argument("--cin", type=int, default=64)
     ap.add_argument("--cout", type=int, default=128)
     ap.add_argument("--hw", type=int, default=56)
+    ap.add_argument("--stride", type=int, default=1, help="2: the phase-plane form (6 steps of 2 / 1 tap rows per 32 channels)")
     a = ap.parse_args()
     assert int(os.environ.get("PLHIP_PATCH_DEBUG", "0")) & 32, "run with PLHIP_PATCH_DEBUG=32"
     rng = np.random.default_rng(0)
     n, cin, cout, hw = a.n, a.cin, a.cout, a.hw
     with capi.Context(0) as ctx:
         L = ctx.L
-        d = capi.conv_desc(n, cin, hw, hw, cout, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1, capi.ACT_RELU, 0.0)
+        d = capi.conv_desc(n, cin, hw, hw, cout, 3, 3, (1, 1, 1, 1), (a.stride, a.stride), (1, 1), 1, capi.ACT_RELU, 0.0)
+        ho = (hw + 2 - 3) // a.stride + 1
         dx = ctx.to_device(rng.integers(-127, 128, (n, cin, hw, hw), dtype=np.int8))
         dw = ctx.to_device(rng.integers(-127, 128, (cout, cin, 3, 3), dtype=np.int8))
         ds = ctx.to_device(np.full(cout, 1e-4, np.float32))
@@ -38,7 +40,7 @@ def main():
         ctx.check(L.plhip_pack_conv_weights(ctx.h, C.byref(d), dw, dwp), "pack")
         wsb = L.plhip_conv_workspace_bytes(C.byref(d))
         dws = ctx.malloc(wsb)
-        dy = ctx.malloc(n * cout * hw * hw)
+        dy = ctx.malloc(n * cout * ho * ho)
         for _ in range(20):
             ctx.check(L.plhip_conv2d_int8(ctx.h, C.byref(d), dx, dwp, ds, db, dy, capi.OUT_I8, dws, wsb), "conv")
         ctx.sync()

@@ -30,7 +30,7 @@ def family(name):
         return "stem_conv"
     if "conv_patch_i8_kernel" in name:
         return "conv3x3_patch"  # dense 3x3 stride-1 convs with whole 32-channel chunks (conv_patch_i8.hip); their padded copy below
-    if "pad_rows8" in name:
+    if "pad_rows8" in name or "pad_phase8" in name:
         return "conv3x3_patch_pad"
     if "gemm_i8_tr_kernel" in name:
         return "conv_implicit_gemm"  # dense k x k convs (the implicit-GEMM route); 1x1 convs never use this kernel by default

@@ -31,7 +31,8 @@ for f in ("bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.j
           "opbench_b256.txt", "opbench_pw_wide_off.txt", "wide_timeline_pw8.txt", "wide_timeline_pw6.txt", "wide_timeline_pw13.txt",
           "wide_timeline_pw14.txt", "gemm_timeline_pw8_ring.txt", "c2bench.txt", "pmc_sq_c3.csv", "pmc_sq_c4.csv",
           "bench_driver_form.json", "opbench_resnet50_3x3.txt", "opbench_resnet50_3x3_patch_off.txt", "opbench_resnet50_3x3_no_epilogue.txt",
-          "opbench_dw5x5.txt", "patch_timeline_c2.txt", "patch_timeline_res2.txt", "patch_timeline_res4.txt"):
+          "opbench_dw5x5.txt", "opbench_dw5x5_lds_band.txt", "opbench_resnet50_3x3_s2_patch_off.txt", "patch_timeline_res3a_s2.txt",
+          "patch_timeline_res5a_s2.txt", "patch_timeline_c2.txt", "patch_timeline_res2.txt", "patch_timeline_res4.txt"):
     if os.path.exists(os.path.join(E, f)):
         cp(f, f)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -48,6 +49,8 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             o.write('"%s",%d,%.1f,%.1f\n' % (k, n, v, v / n))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(E, "fetch"),
                        os.path.join(E, "write"), os.path.join(P, "pmc_traffic.json")], stdout=subprocess.DEVNULL)
+if os.path.isdir(os.path.join(E, "stats_s2")):
+    cp("stats_s2/p_kernel_stats.csv", "kernel_stats_s2_layers.csv")
 if os.path.isdir(os.path.join(E, "stats_c2")):
     cp("stats_c2/p_kernel_stats.csv", "kernel_stats_c2bench.csv")
 if os.path.isdir(os.path.join(E, "fetch_c2")):
