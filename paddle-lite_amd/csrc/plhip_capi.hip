@@ -44,7 +44,7 @@ plhip_status fail(plhip_ctx* c, plhip_status st, const char* fmt, const char* a 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
-enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2, IMPL_IMPLICIT_GEMM = 3, IMPL_PATCH_GEMM = 4, IMPL_PATCH_S2 = 5 };
+enum ConvImpl { IMPL_GEMM_1X1 = 0, IMPL_DIRECT_3X3S2 = 1, IMPL_IM2COL_GEMM = 2, IMPL_IMPLICIT_GEMM = 3, IMPL_PATCH_GEMM = 4, IMPL_PATCH_S2 = 5, IMPL_STEM_7X7S2 = 6 };
 
 struct ConvGeom {
   int oh, ow, G, Mg, Cg, Kg, N, Np, MA, MT, MT32, KS;
@@ -129,7 +129,11 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   else if (plhip::conv3x3s2_direct_supported(d->cin, d->cout, d->kh, d->kw, d->stride[0], d->stride[1], d->dil[0], d->dil[1],
                                              d->groups, d->pad[2]))
     g->impl = IMPL_DIRECT_3X3S2;
-  else g->impl = IMPL_IM2COL_GEMM;
+  else if (plhip::conv7x7s2_stem_supported(d->cin, d->cout, d->kh, d->kw, d->stride[0], d->stride[1], d->dil[0], d->dil[1],
+                                           d->groups, d->n, d->h, d->w, g->oh, g->ow, d->pad[2])) {
+    g->impl = IMPL_STEM_7X7S2;  // ResNet50's stem: direct (conv_stem7_i8.hip), no padded copy
+    return true;
+  } else g->impl = IMPL_IM2COL_GEMM;
   // dense k x k stride-1 convs whose GEMM fits the LDS-DMA ring kernel (64-row wave tiles: M > 128, 32-row tiles: 96 < M <=
   // 128 with K >= 256) skip the im2col buffer: implicit GEMM on a zero-padded copy of the input (1.08x the input
   // instead of kh*kw x: BASELINE config #2 spent 128 of 149 us writing its 57.8 MB im2col buffer)
@@ -321,6 +325,7 @@ size_t plhip_conv_packed_weight_bytes(const plhip_conv_desc* d) {
   if (g.impl == IMPL_DIRECT_3X3S2) return plhip::conv3x3s2_direct_packed_bytes(d->cin, d->cout);
   if (g.impl == IMPL_PATCH_GEMM) return plhip::conv_patch_packed_bytes(d->cin, d->cout);
   if (g.impl == IMPL_PATCH_S2) return plhip::conv_patch_s2_packed_bytes(d->cin, d->cout);
+  if (g.impl == IMPL_STEM_7X7S2) return plhip::conv7x7s2_stem_packed_bytes(d->cout);
   return (size_t)g.G * g.MT32 * g.KS * 1024;
 }
 
@@ -335,6 +340,8 @@ plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d, c
     plhip::launch_pack_conv_patch(w_oihw, (int8_t*)w_packed, d->cin, d->cout, ctx->stream);
   } else if (g.impl == IMPL_PATCH_S2) {
     plhip::launch_pack_conv_patch_s2(w_oihw, (int8_t*)w_packed, d->cin, d->cout, ctx->stream);
+  } else if (g.impl == IMPL_STEM_7X7S2) {
+    plhip::launch_pack_conv7x7s2_stem(w_oihw, (int8_t*)w_packed, d->cin, d->cout, ctx->stream);
   } else {
     plhip::launch_pack_weights(w_oihw, (int8_t*)w_packed, g.G, g.Mg, g.Kg, g.MT32, g.KS, ctx->stream);
   }
@@ -361,6 +368,7 @@ const char* plhip_conv_impl_name(const plhip_conv_desc* d) {
   if (g.impl == IMPL_IMPLICIT_GEMM) return "conv_implicit_gemm_int8_mfma32x32x32";
   if (g.impl == IMPL_PATCH_GEMM) return "conv_patch_gemm_int8_mfma32x32x32";
   if (g.impl == IMPL_PATCH_S2) return "conv_patch_s2_gemm_int8_mfma32x32x32";
+  if (g.impl == IMPL_STEM_7X7S2) return "conv_7x7s2_direct_int8_mfma32x32x32";
   return "conv_im2col_gemm_int8_mfma32x32x32";
 }
 
@@ -404,6 +412,23 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     a.oh = g.oh; a.ow = g.ow; a.pt = d->pad[0]; a.pl = d->pad[2]; a.act = d->act; a.alpha = d->act_alpha;
     plhip::launch_conv3x3s2_direct(a, (int)out, ctx->stream);
     LAUNCHCHK(ctx, "conv3x3s2_direct");
+    return PLHIP_OK;
+  }
+  if (g.impl == IMPL_STEM_7X7S2) {
+    if (!aligned(w_packed, 16)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_int8: packed weights must be 16-byte aligned");
+    plhip::DirectS2Args a;
+    a.x = x;
+    a.wp = (const uint32_t*)w_packed;
+    a.y = y;
+    a.scale = scale;
+    a.bias = bias;
+    a.n = d->n; a.cin = d->cin; a.h = d->h; a.w = d->w; a.cout = d->cout; a.coutp = rup(d->cout, 4);
+    a.oh = g.oh; a.ow = g.ow; a.pt = d->pad[0]; a.pl = d->pad[2]; a.act = d->act; a.alpha = d->act_alpha;
+    a.res = t_res; a.res_relu = t_relu; a.y2 = t_y2; a.inv_scale2 = t_inv;
+    const size_t esz_s = out == PLHIP_OUT_I8 ? 1 : 4;
+    const bool vec = aligned(y, 4 * esz_s) && aligned(t_res, 16) && aligned(t_y2, 4);
+    plhip::launch_conv7x7s2_stem(a, (int)out, vec, ctx->stream);
+    LAUNCHCHK(ctx, "conv7x7s2_stem");
     return PLHIP_OK;
   }
   if (g.impl == IMPL_PATCH_GEMM || g.impl == IMPL_PATCH_S2) {

@@ -191,7 +191,18 @@ struct DirectS2Args {
   int n, cin, h, w, cout, coutp, oh, ow, pt, pl;
   int act;
   float alpha;
+  // fused tail of an fp32-output conv (the 7x7 stem only), as GemmArgs
+  const float* res = nullptr;
+  int res_relu = 0;
+  int8_t* y2 = nullptr;
+  float inv_scale2 = 0.f;
 };
+// conv_stem7_i8.hip: 7x7 stride 2, Cin <= 3 (ResNet50's stem); wp = its A fragments
+bool conv7x7s2_stem_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int n, int h, int w,
+                              int oh, int ow, int pl);
+size_t conv7x7s2_stem_packed_bytes(int cout);
+void launch_pack_conv7x7s2_stem(const int8_t* w_oihw, int8_t* wp, int cin, int cout, hipStream_t s);
+void launch_conv7x7s2_stem(const DirectS2Args& a, int out, bool vec_store, hipStream_t s);
 bool conv3x3s2_direct_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int pl);
 size_t conv3x3s2_direct_packed_bytes(int cin, int cout);
 void launch_pack_conv3x3s2_direct(const int8_t* w_oihw, uint32_t* wp, int cin, int cout, hipStream_t s);

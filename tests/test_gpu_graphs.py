@@ -298,7 +298,8 @@ def test_implicit_gemm_stride2_phase_split(gpu_ctx, plref, pkg):
     capi = pkg.capi
     rng = np.random.default_rng(331)
     cases = [  # n, cin, cout, h, w, k, pads(t, b, l, r)
-        (2, 3, 64, 64, 64, 7, (3, 3, 3, 3)),       # the stem's shape class (K = 147)
+        (2, 3, 64, 64, 64, 7, (3, 3, 3, 3)),       # the stem's shape class (K = 147): direct kernel
+        (2, 4, 64, 64, 64, 7, (3, 3, 3, 3)),       # Cin = 4 (28 filter rows): stays on the implicit GEMM
         (2, 32, 64, 28, 28, 3, (1, 1, 1, 1)),      # res3a/4a/5a branch2b class
         (3, 16, 48, 15, 17, 3, (1, 1, 1, 1)),      # odd extents
         (2, 16, 40, 14, 14, 3, (0, 1, 0, 1)),      # asymmetric pads, 7-column output rows
@@ -312,6 +313,8 @@ def test_implicit_gemm_stride2_phase_split(gpu_ctx, plref, pkg):
         wsc = ((1 + np.arange(cout) % 5) / 127.0 / 4.0).astype(np.float32)
         d = capi.conv_desc(n, cin, h, wd, cout, k, k, pads, (2, 2), (1, 1), 1, capi.ACT_RELU, 0.0)
         want = "conv_patch_s2_gemm" if (k == 3 and cin % 32 == 0 and cout > 64) else "conv_implicit_gemm"
+        if k == 7 and cin <= 3:
+            want = "conv_7x7s2_direct"  # the stem's own kernel (conv_stem7_i8.hip)
         assert capi.load().plhip_conv_impl_name(d).decode().startswith(want), (cin, cout, h, k)
         s = plref.shape(n, cin, h, wd, cout, k, k, pads, (2, 2), (1, 1), 1)
         acc_ref = plref.conv2d_acc(s, x, w)

@@ -395,6 +395,23 @@ def test_patch_conv_stride2_route(gpu_ctx, pkg, plref):
                                 act != 4, rng) == 1, (n, cin, h, w, cout, pads, act)
 
 
+def test_stem_7x7_stride2_direct(gpu_ctx, pkg, plref):
+    """7x7 stride-2 convs with Cin <= 3 and OW % 4 == 0 on the direct stem kernel (conv_stem7_i8.hip; ResNet50's conv1): the
+    network shape, Cin 1 / 2 / 3, M tails and several m tiles, odd heights, asymmetric / zero pads, rows narrower than a quad
+    tile, single-row-group tensors (every block fetches bytewise), every activation and output kind."""
+    rng = np.random.default_rng(141)
+    capi = pkg.capi
+    cases = [  # n, cin, h, w, cout, pads(t,b,l,r), act
+        (2, 3, 224, 224, 64, (3, 3, 3, 3), 1), (3, 3, 64, 64, 64, (3, 3, 3, 3), 2), (2, 1, 41, 64, 40, (3, 3, 3, 3), 0),
+        (2, 2, 65, 64, 96, (3, 2, 3, 2), 4), (1, 3, 30, 69, 33, (0, 0, 0, 0), 1), (5, 3, 18, 32, 64, (3, 3, 3, 3), 1),
+        (1, 3, 9, 16, 8, (3, 3, 3, 3), 0), (2, 3, 112, 522, 32, (2, 3, 1, 2), 2)]
+    for (n, cin, h, w, cout, pads, act) in cases:
+        d = capi.conv_desc(n, cin, h, w, cout, 7, 7, pads, (2, 2), (1, 1), 1, act, 0.0)
+        assert gpu_ctx.L.plhip_conv_impl_name(__import__("ctypes").byref(d)) == b"conv_7x7s2_direct_int8_mfma32x32x32", (cin, cout, w, pads)
+        assert _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 7, 7, pads, 2, 1, 1, act, 6.0 if act == 2 else 0.25,
+                                act != 4, rng) == 1, (n, cin, h, w, cout, pads, act)
+
+
 def test_fc_calib_pool_softmax(gpu_ctx, pkg, plref):
     capi = pkg.capi
     g = load_golden(golden_files("fc_")[0])

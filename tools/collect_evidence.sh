@@ -54,7 +54,7 @@ PLHIP_GEMM_WIDE=0 PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/gemm_timeli
 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3.txt || exit 1
 PLHIP_CONV_PATCH=0 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_patch_off.txt || exit 1
 PLHIP_PATCH_DEBUG=1 timeout -k 10 200 python tools/opbench.py all --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_no_epilogue.txt || exit 1
-PLHIP_CONV_PATCH_S2=0 timeout -k 10 200 python tools/opbench.py s2 --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_s2_patch_off.txt || exit 1
+PLHIP_CONV_PATCH_S2=0 PLHIP_STEM7=0 timeout -k 10 200 python tools/opbench.py s2 --net resnet50_3x3 --batch 256 2>&1 | cut -c1-130 > $O/opbench_resnet50_3x3_s2_patch_off.txt || exit 1
 timeout -k 10 200 python tools/opbench.py all --net dw5x5 2>&1 | cut -c1-110 > $O/opbench_dw5x5.txt || exit 1
 PLHIP_DW5_DIRECT=0 timeout -k 10 200 python tools/opbench.py all --net dw5x5 2>&1 | cut -c1-110 > $O/opbench_dw5x5_lds_band.txt || exit 1
 PLHIP_PATCH_DEBUG=32 timeout -k 10 100 python tools/patch_timeline.py > $O/patch_timeline_c2.txt 2>&1 || exit 1

@@ -58,7 +58,8 @@ def main():
         elif args.net == "resnet50_3x3":
             layers = [("c2", "conv2d", 64, 128, 3, 1, 1, 1, 56), ("res2", "conv2d", 64, 64, 3, 1, 1, 1, 56), ("res3", "conv2d", 128, 128, 3, 1, 1, 1, 28),
                       ("res4", "conv2d", 256, 256, 3, 1, 1, 1, 14), ("res5", "conv2d", 512, 512, 3, 1, 1, 1, 7), ("res3a", "conv2d", 128, 128, 3, 2, 1, 1, 56),
-                      ("res4a", "conv2d", 256, 256, 3, 2, 1, 1, 28), ("res5a", "conv2d", 512, 512, 3, 2, 1, 1, 14)]
+                      ("res4a", "conv2d", 256, 256, 3, 2, 1, 1, 28), ("res5a", "conv2d", 512, 512, 3, 2, 1, 1, 14),
+                      ("stem7", "conv2d", 3, 64, 7, 2, 3, 1, 224)]
         else:
             layers = wl.mobilenet_v1_layers()
         for (name, op, cin, cout, k, s, p, g, hin) in layers:

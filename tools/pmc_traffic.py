@@ -26,7 +26,7 @@ def load(d, counter):
 def family(name):
     if "depthwise" in name:
         return "depthwise3x3"
-    if "conv3x3s2" in name:
+    if "conv3x3s2" in name or "conv7x7s2_stem" in name:
         return "stem_conv"
     if "conv_patch_i8_kernel" in name:
         return "conv3x3_patch"  # dense 3x3 stride-1 convs with whole 32-channel chunks (conv_patch_i8.hip); their padded copy below
