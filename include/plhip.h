@@ -101,10 +101,10 @@ plhip_status plhip_event_destroy(plhip_ctx* ctx, void* event);
 size_t plhip_conv_packed_weight_bytes(const plhip_conv_desc* d);
 plhip_status plhip_pack_conv_weights(plhip_ctx* ctx, const plhip_conv_desc* d,
                                      const int8_t* w_oihw, void* w_packed);
-/* Scratch (0 for 1x1 s1 p0 and the 3x3 s2 stem): the zero-padded input copy of the implicit-GEMM route (dense k x k,
- * stride 1, wide enough GEMM: ~1.1x the input) or the im2col buffer (everything else: kh*kw x the input); replaces
- * ctx.workspace_data (conv_gemmlike.cc:131).  The caller passes at least this many bytes, 16-byte aligned (4 suffices
- * for every route but the dense 3x3 stride-1 patch kernel's padded copy). */
+/* Scratch (0 for 1x1 s1 p0 and the small-Cin 3x3 / 7x7 s2 stems): the zero-padded input copy of the implicit-GEMM route
+ * (dense k x k, stride 1 or 2, wide enough GEMM: ~1.1x the input) or the im2col buffer (everything else: kh*kw x the
+ * input); replaces ctx.workspace_data (conv_gemmlike.cc:131).  The caller passes at least this many bytes, 16-byte aligned
+ * (4 suffices for every route but the dense 3x3 patch kernel's padded / phase-split copy). */
 size_t plhip_conv_workspace_bytes(const plhip_conv_desc* d);
 /* scale/bias: folded per-output-channel fp32 arrays of length cout; bias may be NULL
  * (treated as zeros).  y: int32 / float / int8 NCHW according to `out`.  For PLHIP_OUT_I32_ACC scale,

@@ -468,6 +468,45 @@ def test_patch_conv_random_shapes(gpu_ctx, pkg, plref):
     assert done >= 20, done
 
 
+def test_new_route_random_shapes(gpu_ctx, pkg, plref):
+    """Random sweeps (the reference's random grid, conv_int8_compute_test.cc:676-731, narrowed to each kernel's shape space) over
+    the stride-2 patch kernel (Cin 32-160 in 32s, Cout 65-260, 5-120 rows / columns, pads 0-2), the 7x7 stride-2 stem (Cin 1-3,
+    Cout 8-100, OW % 4 == 0, pads 0-3) and the direct depthwise 5x5 kernel (1-70 channels, stride 1 / 2, pads 0-3, 5-60 rows /
+    columns): every activation, bias on / off."""
+    rng = np.random.default_rng(143)
+    capi = pkg.capi
+    byref = __import__("ctypes").byref
+    done = [0, 0, 0]
+    for _ in range(40):
+        cin, cout = int(rng.choice([32, 64, 96, 128, 160])), int(rng.integers(65, 261))
+        n, h, w = int(rng.integers(1, 8)), int(rng.integers(5, 121)), int(rng.integers(5, 121))
+        pads = tuple(int(v) for v in rng.integers(0, 3, 4))
+        act = int(rng.choice([0, 1, 2, 4]))
+        d = capi.conv_desc(n, cin, h, w, cout, 3, 3, pads, (2, 2), (1, 1), 1, act, 0.0)
+        if gpu_ctx.L.plhip_conv_impl_name(byref(d)) != b"conv_patch_s2_gemm_int8_mfma32x32x32" or n * cout * h * w * cin > 1.0e9:
+            continue
+        done[0] += _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 3, 3, pads, 2, 1, 1, act, 6.0 if act == 2 else 0.25,
+                                    bool(rng.integers(0, 2)), rng)
+    for _ in range(40):
+        cin, cout = int(rng.integers(1, 4)), int(rng.integers(8, 101))
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(7, 150)), int(rng.integers(16, 200))
+        pads = tuple(int(v) for v in rng.integers(0, 4, 4))
+        act = int(rng.choice([0, 1, 2, 4]))
+        d = capi.conv_desc(n, cin, h, w, cout, 7, 7, pads, (2, 2), (1, 1), 1, act, 0.0)
+        if gpu_ctx.L.plhip_conv_impl_name(byref(d)) != b"conv_7x7s2_direct_int8_mfma32x32x32":
+            continue  # (OW % 4 != 0: the implicit GEMM)
+        done[1] += _check_all_kinds(gpu_ctx, capi, plref, n, cin, h, w, cout, 7, 7, pads, 2, 1, 1, act, 6.0 if act == 2 else 0.25,
+                                    bool(rng.integers(0, 2)), rng)
+    for _ in range(40):
+        c, st = int(rng.integers(1, 71)), int(rng.integers(1, 3))
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(5, 61)), int(rng.integers(5, 61))
+        pads = tuple(int(v) for v in rng.integers(0, 4, 4))
+        act = int(rng.choice([0, 1, 2, 4]))
+        done[2] += _check_all_kinds(gpu_ctx, capi, plref, n, c, h, w, c, 5, 5, pads, st, 1, c, act, 6.0 if act == 2 else 0.3,
+                                    bool(rng.integers(0, 2)), rng, depthwise=True)
+    assert done[0] >= 12 and done[1] >= 6 and done[2] >= 30, done
+
+
 def test_full_size_properties_c2(gpu_ctx, pkg, plref):
     """BASELINE config #2 at full size (N=32, 64->128, 56x56, k3 s1 p1): too big for the scalar oracle in
     seconds, so check size-independent properties: (i) linearity in the weights acc(w1+w2) = acc(w1)+acc(w2);
