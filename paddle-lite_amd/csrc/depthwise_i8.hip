@@ -225,15 +225,18 @@ __global__ __launch_bounds__(256) void depthwise_i8_kernel(DwArgs a) {
 //   * the 4 sliding windows are cut with v_alignbyte_b32 and hit the packed filter row with v_dot4_i32_i8; each input
 //     row's windows are reused for the (up to) 3 output rows it feeds;
 //   * no LDS, no barrier, no shuffles; image borders are handled by per-lane byte masks (zero padding).
+// One output row of a lane's strip: `rowbase` = the output tensor advanced by the row's offset inside the strip (wave-uniform:
+// the stores take it as their scalar base), `off` = the lane's element offset of (plane, strip row 0, quad) — no per-row
+// 64-bit address arithmetic; the clamp bound and the rounding constant are scalar kernel arguments (a.hi2, a.ones).
 template <int OUT, int ACT>
-__device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int room, const int (&acc)[4], float s, float bi) {
+__device__ __forceinline__ void dw_finish_row(const DwArgs& a, void* rowbase, uint32_t off, int room, const int (&acc)[4], float s, float bi) {
   if (OUT == OUT_I32) {
-    int* yp = reinterpret_cast<int*>(a.y) + off;
+    int* yp = reinterpret_cast<int*>(rowbase) + off;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < room) yp[j] = acc[j];
   } else if (OUT == OUT_F32) {
-    float* yp = reinterpret_cast<float*>(a.y) + off;
+    float* yp = reinterpret_cast<float*>(rowbase) + off;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float f = __fmaf_rn((float)acc[j], s, bi);
@@ -243,10 +246,9 @@ __device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int r
       if (j < room) yp[j] = f;
     }
   } else {
-    const float hi2 = ACT == ACT_RELU6 ? fminf(a.alpha + a.alpha, 254.f) : 254.f;
     const float lo2 = (ACT == ACT_RELU || ACT == ACT_RELU6) ? 0.f : -254.f;
-    const uint32_t pk = dw_requant4<ACT>(acc, s + s, bi + bi, a.alpha, lo2, hi2);
-    int8_t* yp = reinterpret_cast<int8_t*>(a.y) + off;
+    const uint32_t pk = dw_requant4<ACT>(acc, s + s, bi + bi, a.alpha, lo2, a.hi2, a.ones);
+    int8_t* yp = reinterpret_cast<int8_t*>(rowbase) + off;
     if (room >= 4) {
       __builtin_memcpy(yp, &pk, 4);  // may be unaligned when OW % 4 != 0: fine for global memory
     } else {
@@ -262,7 +264,7 @@ __device__ __forceinline__ void dw_finish_row(const DwArgs& a, size_t off, int r
 // of a wave own one CONTIGUOUS output region ((64/owq) strips x RS rows x OW bytes); the results are assembled in LDS
 // and leave as contiguous dwords (256 B per store instruction).
 // KS = 3 or 5 (square filter): the window of 4 outputs is 3 S + KS bytes = 2 dwords at stride 1, 3 at stride 2 for both.
-template <int OUT, int S, int RS, bool STAGE, int KS>
+template <int OUT, int S, int RS, bool STAGE, int KS, bool FULLROWS>
 __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&in)[(RS - 1) * S + KS][S == 1 ? 2 : 3], long plane,
                                              int ch, int oy0, int xq, bool live, long gid_in, uint8_t* wlds);
 
@@ -321,12 +323,13 @@ __device__ __forceinline__ void dw3x3_direct_body(const DwArgs& a, long gid_in, 
 #pragma unroll
   for (int t = 0; t < NIN; ++t) dw_load_row<ND, TAIL>(xplane, iy0 + t, a.h, a.w, lcol, sh, plane_room, cmask, in[t]);
 
-  dw3x3_finish<OUT, S, RS, STAGE, KS>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
+  dw3x3_finish<OUT, S, RS, STAGE, KS, false>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
 }
 
 // Second half of a strip, shared by the general and the fast row fetch: filter / scale fetch, the dot4 accumulation
 // over the NIN input rows in registers, requantisation and the store (direct, or staged through LDS).
-template <int OUT, int S, int RS, bool STAGE, int KS>
+// FULLROWS: every strip has all its RS rows (RS | OH: the fast-fetch launches): no per-row test.
+template <int OUT, int S, int RS, bool STAGE, int KS, bool FULLROWS>
 __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&in)[(RS - 1) * S + KS][S == 1 ? 2 : 3], long plane,
                                              int ch, int oy0, int xq, bool live, long gid_in, uint8_t* wlds) {
   constexpr int NIN = (RS - 1) * S + KS;
@@ -406,11 +409,10 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
   if (STAGE && OUT == OUT_I8) {
     // requantise into registers first (one straight-line body per activation), then LDS, then contiguous stores
     uint32_t pk[RS];
-    const float hi2r = 254.f, s2 = sc + sc, b2 = bi + bi;
+    const float s2 = sc + sc, b2 = bi + bi;
 #define DW_PK(ACTV)                                                                                                  \
   _Pragma("unroll") for (int o = 0; o < RS; ++o) pk[o] =                                                             \
-      dw_requant4<ACTV>(acc[o], s2, b2, a.alpha, (ACTV == ACT_RELU || ACTV == ACT_RELU6) ? 0.f : -254.f,             \
-                        ACTV == ACT_RELU6 ? fminf(a.alpha + a.alpha, 254.f) : hi2r);
+      dw_requant4<ACTV>(acc[o], s2, b2, a.alpha, (ACTV == ACT_RELU || ACTV == ACT_RELU6) ? 0.f : -254.f, a.hi2, a.ones);
     switch (a.act) {
       case ACT_RELU: DW_PK(ACT_RELU) break;
       case ACT_RELU6: DW_PK(ACT_RELU6) break;
@@ -469,9 +471,12 @@ __device__ __forceinline__ void dw3x3_finish(const DwArgs& a, const uint32_t (&i
     for (int i = head + 4 * ndw + lane; i < region; i += 64) yb[i] = (int8_t)wlds[i];
     return;
   }
-#define DW_ROWS(ACTV)                                                                              \
-  _Pragma("unroll") for (int o = 0; o < RS; ++o) {                                                 \
-    if (oy0 + o < a.oh) dw_finish_row<OUT, ACTV>(a, obase + (size_t)o * a.ow, room, acc[o], sc, bi); \
+  constexpr int ESZ = OUT == OUT_I8 ? 1 : 4;
+  const uint32_t obase32 = (uint32_t)obase;  // < 2^31 elements (launcher check)
+#define DW_ROWS(ACTV)                                                                                                   \
+  _Pragma("unroll") for (int o = 0; o < RS; ++o) {                                                                      \
+    if (FULLROWS || oy0 + o < a.oh)                                                                                     \
+      dw_finish_row<OUT, ACTV>(a, reinterpret_cast<uint8_t*>(a.y) + (size_t)(o * a.ow) * ESZ, obase32, room, acc[o], sc, bi); \
   }
   if (OUT == OUT_I32) {
     DW_ROWS(ACT_NONE)
@@ -544,7 +549,7 @@ __device__ __forceinline__ void dw3x3_fast_body(const DwArgs& a, long gid_in, bo
       if (t < PV || t >= NIN - PV) m = ok[t] ? m : 0u;
       in[t][d] &= m;
     }
-  dw3x3_finish<OUT, S, RS, STAGE, KS>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
+  dw3x3_finish<OUT, S, RS, STAGE, KS, true>(a, in, plane, ch, oy0, xq, live, gid_in, wlds);
 }
 
 template <int OUT, int S, int RS, bool STAGE, bool FASTV, int KS>
@@ -552,7 +557,7 @@ __device__ __forceinline__ void dw_direct_kernel_body(DwArgs a) {
   PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.wt); PLHIP_PRELOAD(a.y); PLHIP_PRELOAD(a.scale); PLHIP_PRELOAD(a.bias);
   PLHIP_PRELOAD(a.planes); PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.h); PLHIP_PRELOAD(a.w); PLHIP_PRELOAD(a.oh); PLHIP_PRELOAD(a.ow);
   PLHIP_PRELOAD(a.pt); PLHIP_PRELOAD(a.pl); PLHIP_PRELOAD(a.total_lanes); PLHIP_PRELOAD(a.owq_log2); PLHIP_PRELOAD(a.spp_log2);
-  PLHIP_PRELOAD(a.fast_div); PLHIP_PRELOAD(a.stage_bytes); PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha); PLHIP_PRELOAD(a.lw); PLHIP_PRELOAD(a.nblocks);
+  PLHIP_PRELOAD(a.fast_div); PLHIP_PRELOAD(a.stage_bytes); PLHIP_PRELOAD(a.act); PLHIP_PRELOAD(a.alpha); PLHIP_PRELOAD(a.lw); PLHIP_PRELOAD(a.nblocks); PLHIP_PRELOAD(a.hi2); PLHIP_PRELOAD(a.ones);
   PLHIP_PRELOAD(a.div_owq_m); PLHIP_PRELOAD(a.div_spp_m); PLHIP_PRELOAD(a.div_c_m); PLHIP_PRELOAD(a.div_owq_s); PLHIP_PRELOAD(a.div_spp_s); PLHIP_PRELOAD(a.div_c_s);
   extern __shared__ __attribute__((aligned(16))) uint8_t dw_stage[];  // STAGE: 4 waves x stage_bytes
   // XCD-contiguous work: workgroups are dealt round-robin over the 8 XCDs (private L2 each); giving XCD x the x-th eighth
@@ -593,6 +598,8 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
   const long total = (long)a_in.planes * spp * owq;
   DwArgs a = a_in;
   a.total_lanes = total;
+  a.hi2 = a.act == ACT_RELU6 ? (a.alpha + a.alpha < 254.f ? a.alpha + a.alpha : 254.f) : 254.f;
+  a.ones = 0x01010101u;
   auto lg2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return (1L << l) == v ? l : -1; };
   a.owq_log2 = lg2(owq);
   a.spp_log2 = lg2(spp);

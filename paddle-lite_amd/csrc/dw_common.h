@@ -10,14 +10,17 @@ __device__ __forceinline__ uint32_t fastdiv_u31(uint32_t n, uint32_t magic, int 
   return magic ? (__umulhi(n, magic) >> sh) : (n >> sh);
 }
 
+// ones: 0x01010101 (the byte-wise +1 of the packed rounding) — a parameter so that a caller can hand over a scalar kernel
+// argument instead of a constant the compiler moves into a VGPR again per use
 template <int ACT>
-__device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, float b2, float alpha, float lo2, float hi2) {
+__device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, float b2, float alpha, float lo2, float hi2,
+                                                uint32_t ones = 0x01010101u) {
   if (ACT == ACT_RELU || ACT == ACT_RELU6) {
     uint32_t t[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) t[j] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)a[j], s2, b2), lo2, hi2);
     const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-    return round_half_up4_u8(p);
+    return __builtin_amdgcn_lerp(p, 0u, ones);  // round_half_up4_u8 (plhip_device.h)
   }
   int q[4];
 #pragma unroll

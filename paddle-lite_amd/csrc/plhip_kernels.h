@@ -142,6 +142,10 @@ struct DwArgs {
   int lw, nblocks;                // direct kernel: lanes of a wave that own work (staging: whole strips), workgroups of work
   int act;
   float alpha;
+  // direct kernels, set by their launcher: the int8 clamp's upper bound on doubled values (relu6: min(2 alpha, 254)) and the
+  // byte-wise +1 of the packed rounding, as kernel arguments = scalar operands (the compiler re-made both per output row)
+  float hi2 = 254.f;
+  unsigned ones = 0x01010101u;
 };
 
 // fused depthwise 3x3 (int8 out) -> pointwise 1x1
