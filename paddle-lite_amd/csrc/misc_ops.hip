@@ -335,12 +335,18 @@ void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s)
 
 void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const float* bias, void* y, int m, int k, int n,
                int relu, int out, hipStream_t s) {
+  // The MFMA form is NOT the default any more: measured again at the end of round 3 (tools/fcbench.py, one box) the dot4
+  // kernel below that stages x through LDS runs the network tails in half its time (m = 128, k = 1024, n = 1000: 8.8 vs
+  // 18.7 us; 256 x 2048: 16.2 vs 30.9; 1024 x 1280: 22.3 vs 32.3): a lane of the MFMA form fetches its B operand from its own
+  // x row (32 rows 1 KiB apart per load instruction).  PLHIP_FC_MFMA=1 selects it (parity test in a subprocess).
   static int fc_mfma_env = -1;
   if (fc_mfma_env < 0) {
     const char* e = getenv("PLHIP_FC_MFMA");
-    fc_mfma_env = e ? atoi(e) : 1;
+    fc_mfma_env = e ? atoi(e) : 0;
   }
-  if (fc_mfma_env && (k & 31) == 0) {
+  const size_t lds_f = (size_t)FCF_MB * k > (size_t)4 * FCF_MB * 64 * 4 ? (size_t)FCF_MB * k : (size_t)4 * FCF_MB * 64 * 4;
+  const bool fast_ok = (k & 15) == 0 && ((uintptr_t)x & 15) == 0 && lds_f <= 64 * 1024;
+  if ((fc_mfma_env || !fast_ok) && (k & 31) == 0) {
     dim3 grid((n + 31) / 32, (m + 31) / 32);
     const int8_t* wfrag = wp + fc_dot4_bytes(k, n);
     if (out == OUT_I32) hipLaunchKernelGGL((fc_i8_mfma_kernel<OUT_I32>), grid, dim3(256), 0, s, x, wfrag, scale, bias, y, m, k, n, relu);

@@ -106,9 +106,10 @@ class FcCompute : public KernelLite<TARGET(kHIP), Ptype> {
                                       scale_.data<float>(), has_bias_ ? bias_.data<float>() : nullptr,
                                       (relu_ ? 1 : 0) | (gemm_route ? 2 : 0), y, kind));
   }
-  // the library picks the MFMA kernel when k % 32 == 0 (csrc/misc_ops.hip launch_fc), the dot4 kernels otherwise
+  // the library runs the LDS-staged dot4 kernel when k % 16 == 0 (csrc/misc_ops.hip launch_fc), the MFMA form for the
+  // k % 32 == 0 shapes that one cannot take (or under PLHIP_FC_MFMA=1), the plain dot4 kernel otherwise
   void SetProfileRuntimeKernelInfo(profile::OpCharacter* ch) override {
-    ch->kernel_func_name = (k_ % 32 == 0) ? "fc_int8_mfma32x32x32_hip" : "fc_int8_dot4_hip";
+    ch->kernel_func_name = (k_ % 16 == 0 && k_ <= 4096) ? "fc_int8_dot4_lds_hip" : ((k_ % 32 == 0) ? "fc_int8_mfma32x32x32_hip" : "fc_int8_dot4_hip");
   }
 
  private:

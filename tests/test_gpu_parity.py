@@ -395,6 +395,43 @@ def test_patch_conv_stride2_route(gpu_ctx, pkg, plref):
                                 act != 4, rng) == 1, (n, cin, h, w, cout, pads, act)
 
 
+_FC_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+from oracle import plref
+plref.build()
+capi = ge.import_package().capi
+rng = np.random.default_rng(145)
+with capi.Context(0) as ctx:
+    for (m, k, n) in [(5, 1024, 1000), (70, 64, 37), (33, 96, 1000), (128, 1024, 1000), (3, 2048, 130)]:
+        x = rng.integers(-127, 128, (m, k)).astype(np.int8)
+        w = rng.integers(-127, 128, (k, n)).astype(np.int8)
+        sc = ((1 + np.arange(n) %% 5) / 127.0 / 127.0).astype(np.float32)
+        bi = rng.uniform(-1, 1, n).astype(np.float32)
+        y_ref, acc_ref = plref.fc(x, w, bi, sc, False, False)
+        assert np.array_equal(ctx.fc(x, w, None, None, 0, capi.OUT_I32), acc_ref), (m, k, n)
+        np.testing.assert_allclose(ctx.fc(x, w, sc, bi, 0, capi.OUT_F32), y_ref, rtol=1e-5, atol=1e-7)
+        sc8 = (sc * 40.0).astype(np.float32)
+        y8_ref, _ = plref.fc(x, w, bi, sc8, True, True)
+        assert np.array_equal(ctx.fc(x, w, sc8, bi, 1, capi.OUT_I8), y8_ref), (m, k, n)
+print("fc mfma form ok")
+"""
+
+
+def test_fc_mfma_form_in_a_subprocess(gpu_ctx):
+    """The MFMA form of fc (k % 32 == 0) is no longer what the library picks by default (the LDS-staged dot4 kernel runs the
+    network tails in half its time); it stays selectable (PLHIP_FC_MFMA=1, read once per process): its parity against the
+    oracle runs in a child process with the variable set."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLHIP_FC_MFMA="1")
+    r = subprocess.run([sys.executable, "-c", _FC_CHILD % root], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fc mfma form ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_stem_7x7_stride2_direct(gpu_ctx, pkg, plref):
     """7x7 stride-2 convs with Cin <= 3 and OW % 4 == 0 on the direct stem kernel (conv_stem7_i8.hip; ResNet50's conv1): the
     network shape, Cin 1 / 2 / 3, M tails and several m tiles, odd heights, asymmetric / zero pads, rows narrower than a quad
