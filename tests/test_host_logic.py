@@ -59,6 +59,15 @@ def test_descriptor_helpers(pkg):
     assert lib.plhip_conv_impl_name(ctypes.byref(s2b)) == b"conv_implicit_gemm_int8_mfma32x32x32"
     s2c = capi.conv_desc(32, 64, 56, 56, 64, 3, 3, (1, 1, 1, 1), (2, 2), (1, 1), 1)
     assert lib.plhip_conv_impl_name(ctypes.byref(s2c)) == b"conv_implicit_gemm_int8_mfma32x32x32"
+    # ResNet50's 7x7 stride-2 stem (Cin <= 3, OW % 4 == 0): its own direct kernel, no workspace, 6 K-steps of A fragments per m tile
+    st7 = capi.conv_desc(256, 3, 224, 224, 64, 7, 7, (3, 3, 3, 3), (2, 2), (1, 1), 1)
+    assert lib.plhip_conv_impl_name(ctypes.byref(st7)) == b"conv_7x7s2_direct_int8_mfma32x32x32"
+    assert lib.plhip_conv_workspace_bytes(ctypes.byref(st7)) == 0
+    assert lib.plhip_conv_packed_weight_bytes(ctypes.byref(st7)) == 2 * 6 * 1024
+    st7b = capi.conv_desc(2, 4, 224, 224, 64, 7, 7, (3, 3, 3, 3), (2, 2), (1, 1), 1)  # 28 filter rows: the implicit GEMM
+    assert lib.plhip_conv_impl_name(ctypes.byref(st7b)) == b"conv_implicit_gemm_int8_mfma32x32x32"
+    st7c = capi.conv_desc(2, 3, 224, 226, 64, 7, 7, (3, 3, 3, 3), (2, 2), (1, 1), 1)  # OW = 113: not whole quads
+    assert lib.plhip_conv_impl_name(ctypes.byref(st7c)) == b"conv_implicit_gemm_int8_mfma32x32x32"
     dil = capi.conv_desc(32, 64, 56, 56, 128, 3, 3, (2, 2, 2, 2), (1, 1), (2, 2), 1)  # dilation stays on im2col + GEMM
     assert lib.plhip_conv_workspace_bytes(ctypes.byref(dil)) == 32 * 576 * 3136
     assert lib.plhip_conv_impl_name(ctypes.byref(dil)) == b"conv_im2col_gemm_int8_mfma32x32x32"
