@@ -142,8 +142,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
             }
           }
           if (g.y2) {  // fused calib fp32 -> int8 of the value just produced
-            const uint32_t packed = pack4_i8(round_sat_i8(g.inv_scale2 * f[0]), round_sat_i8(g.inv_scale2 * f[1]),
-                                             round_sat_i8(g.inv_scale2 * f[2]), round_sat_i8(g.inv_scale2 * f[3]));
+            uint32_t packed;
+            // kernel-uniform: the value is >= 0 (its own relu / relu6 with no residual behind it, or the relu behind the
+            // residual add): round_sat_i8 on doubled values as the int8-output path does it — 2 inv f = fl(inv f) doubled
+            // exactly, t = trunc(min(., 254)), the four (t + 1) >> 1 in one v_lerp_u8: 4 VALU per output instead of ~7.75
+            const bool nonneg = g.res ? g.res_relu != 0 : (ACT == ACT_RELU || ACT == ACT_RELU6);
+            if (nonneg) {
+              const float i2 = g.inv_scale2 + g.inv_scale2;
+              uint32_t t[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) t[i] = (uint32_t)__builtin_amdgcn_fmed3f(i2 * f[i], 0.f, 254.f);
+              packed = round_half_up4_u8((t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16));
+            } else {
+              packed = pack4_i8(round_sat_i8(g.inv_scale2 * f[0]), round_sat_i8(g.inv_scale2 * f[1]),
+                                round_sat_i8(g.inv_scale2 * f[2]), round_sat_i8(g.inv_scale2 * f[3]));
+            }
             int8_t* qp = g.y2 + yoff;
             if (VEC_STORE) {
               *reinterpret_cast<uint32_t*>(qp) = packed;
