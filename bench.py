@@ -403,6 +403,14 @@ def main():
             images = None
 
         P = max(1, args.inflight)
+        # Start offset between the predictors of a window: predictor i submits its first step i * stagger late, stagger = a
+        # P-th of the step time the previous window (first window: the warm-up) measured.  All P predictors are released
+        # together at a window's start; starting level they run the same layers at the same time (three depthwise kernels, then
+        # three GEMMs) until they drift apart, which a 20-step window barely has time for: 308.3 / 309.4 k -> 315.6 / 315.5 k
+        # img/s in the driver's form `--steps 20 --warmup 5` (A/B twice in one call), no change for 300-step windows.
+        # PLHIP_BENCH_STAGGER_US: a fixed offset in us (0 = none).
+        stagger_env = os.environ.get("PLHIP_BENCH_STAGGER_US")
+        stagger = [float(stagger_env) * 1e-6 if stagger_env is not None else 0.0]
         out_bytes = rows * classes * (1 if cfg["model"] == "conv" else 4)
         engines, errs = [None] * P, []
 
@@ -444,6 +452,8 @@ def main():
                         break
                     try:
                         e = engines[self.i]
+                        if stagger[0] > 0.0 and self.i:  # predictors 1.. start their share i * stagger late (see above)
+                            time.sleep(self.i * stagger[0])
                         for s_ in range(self.i, self.n, P):
                             e.run()
                             if use_dist:
@@ -511,7 +521,12 @@ def main():
             if not dry:
                 torch.cuda.synchronize(dev)
 
+        sync_all()
+        tw = time.perf_counter()
         run_steps(args.warmup)
+        sync_all()
+        if stagger_env is None and P > 1 and args.warmup >= P and not dry:
+            stagger[0] = min((time.perf_counter() - tw) / args.warmup / P, 0.005)
         # EXACTLY args.steps steps per timed window, barrier + synchronize on both sides (the contract); the window is repeated
         # back to back and the MEDIAN window is reported: a single 20-step window is ~9 ms here and moved the figure by 3-7 %
         # from run to run.  min / median / max over the windows are in the line.
@@ -527,6 +542,8 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             wins.append(el)
+            if stagger_env is None and P > 1 and not dry:
+                stagger[0] = min(el / args.steps / P, 0.005)
         elapsed = float(np.median(wins))
 
         # ---- outside the timed region: the gathered result of the last step is complete and in rank-major image order ----
