@@ -11,7 +11,9 @@ A step = one pass of the lowered program (calib -> int8 convs [+ fp32 pool / res
 softmax) over one synthetic batch, through the C++ kHIP kernel classes and libplhip.so.  By
 default 3 predictors per GPU (one host thread + HIP stream each, the reference's predictor-per-thread serving model)
 run whole steps, dealt round-robin, so three steps are in flight and fill each other's dispatch gaps (`--inflight 1`:
-strictly serial; also reported as `single_stream`).  Inputs are resident in HBM when the timed region starts.
+strictly serial; also reported as `single_stream`); inside a timed window predictor i submits its first step i/3 of a step
+time late, so that the three do not run the same layer at the same time.  Inputs are resident in HBM when the timed region
+starts.
 
 N > 1: one process per GPU (torch.distributed "nccl" == RCCL over xGMI).  `--gpus N` without a launcher environment
 makes this script start its own N rank processes (fresh children, before anything touches the GPU); under
