@@ -528,7 +528,8 @@ def main():
         run_steps(args.warmup)
         sync_all()
         if stagger_env is None and P > 1 and args.warmup >= P and not dry:
-            stagger[0] = min((time.perf_counter() - tw) / args.warmup / P, 0.005)
+            # (the warm-up's own time may include first-touch costs: its estimate is capped low; later windows measure)
+            stagger[0] = min((time.perf_counter() - tw) / args.warmup / P, 0.0002)
         # EXACTLY args.steps steps per timed window, barrier + synchronize on both sides (the contract); the window is repeated
         # back to back and the MEDIAN window is reported: a single 20-step window is ~9 ms here and moved the figure by 3-7 %
         # from run to run.  min / median / max over the windows are in the line.
