@@ -9,10 +9,10 @@ Default (what the driver runs): config C3 = MobileNetV1-INT8 full graph, batch 1
   c2 = the single conv2d_int8 op (N=32 Cin=64 Cout=128 56x56 k3 s1), N = 1 only.
 A step = one pass of the lowered program (calib -> int8 convs [+ fp32 pool / residual adds] -> pool -> calib -> fc ->
 softmax) over one synthetic batch, through the C++ kHIP kernel classes and libplhip.so.  By
-default 3 predictors per GPU (one host thread + HIP stream each, the reference's predictor-per-thread serving model)
-run whole steps, dealt round-robin, so three steps are in flight and fill each other's dispatch gaps (`--inflight 1`:
-strictly serial; also reported as `single_stream`); inside a timed window predictor i submits its first step i/3 of a step
-time late, so that the three do not run the same layer at the same time.  Inputs are resident in HBM when the timed region
+default 4 predictors per GPU (one host thread + HIP stream each, the reference's predictor-per-thread serving model)
+run whole steps, dealt round-robin, so four steps are in flight and fill each other's dispatch gaps (`--inflight 1`:
+strictly serial; also reported as `single_stream`; 3 was the default until the end of round 3); inside a timed window
+predictor i submits its first step i/4 of a step time late, so that they do not run the same layer at the same time.  Inputs are resident in HBM when the timed region
 starts.
 
 N > 1: one process per GPU (torch.distributed "nccl" == RCCL over xGMI).  `--gpus N` without a launcher environment
@@ -70,7 +70,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the oracle comparison of the last step's output")
     ap.add_argument("--layer-table", action="store_true", help="print the per-instruction timing table to stderr")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="predictors per GPU, each on its own host thread + HIP stream, each running WHOLE steps; the steps "
                          "are dealt round-robin, so --inflight steps are in flight at once (the reference's "
                          "one-predictor-per-thread serving model, cxx_api.h:103-137). 1 = strictly serial steps.")
@@ -409,7 +409,9 @@ def main():
         # P-th of the step time the previous window (first window: the warm-up) measured.  All P predictors are released
         # together at a window's start; starting level they run the same layers at the same time (three depthwise kernels, then
         # three GEMMs) until they drift apart, which a 20-step window barely has time for: 308.3 / 309.4 k -> 315.6 / 315.5 k
-        # img/s in the driver's form `--steps 20 --warmup 5` (A/B twice in one call), no change for 300-step windows.
+        # img/s in the driver's form `--steps 20 --warmup 5` (A/B twice in one call, 3 predictors), no change for 300-step windows.
+        # With the offset a fourth predictor pays (without it 3 and 4 read the same): driver form 308.6 / 306.3 k -> 312.4 / 310.1 k
+        # (c3), 57.1 -> 57.5-57.7 k (c4), 220.0 -> 223.8 k (c5).
         # PLHIP_BENCH_STAGGER_US: a fixed offset in us (0 = none).
         stagger_env = os.environ.get("PLHIP_BENCH_STAGGER_US")
         stagger = [float(stagger_env) * 1e-6 if stagger_env is not None else 0.0]
