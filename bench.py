@@ -456,7 +456,8 @@ def main():
                         break
                     try:
                         e = engines[self.i]
-                        if stagger[0] > 0.0 and self.i:  # predictors 1.. start their share i * stagger late (see above)
+                        if stagger[0] >= 2e-5 and self.i:  # predictors 1.. start their share i * stagger late (see above;
+                            # offsets under 20 us — the single conv of c2 — are below what a host sleep can keep)
                             time.sleep(self.i * stagger[0])
                         for s_ in range(self.i, self.n, P):
                             e.run()
