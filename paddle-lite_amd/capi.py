@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplhip.so")
+LIB_PATH = os.environ.get("PLHIP_LIB_PATH") or os.path.join(_HERE, "libplhip.so")  # override: diagnostic builds only (tools/slp_hazard_variants.py)
 
 OUT_I32, OUT_F32, OUT_I8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 4

@@ -884,7 +884,6 @@ plhip_status plhip_selftest(plhip_ctx* ctx) {
 namespace plhip {
 int debug_read_stamps(void* dst, size_t bytes);
 int debug_read_tr_stamps(void* dst, size_t bytes);
-int debug_read_fz_stamps(void* dst, size_t bytes);
 }
 extern "C" int plhip_debug_read_wide_stamps(void* dst_host, size_t bytes) {
   if (!dst_host) return -1;
@@ -899,10 +898,6 @@ extern "C" void plhip_debug_wide_ntt(int v) { plhip::debug_set_wide_ntt(v); }
 extern "C" int plhip_debug_read_tr_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();
   return plhip::debug_read_tr_stamps(dst_host, bytes);
-}
-extern "C" int plhip_debug_read_fz_stamps(void* dst_host, size_t bytes) {
-  (void)hipDeviceSynchronize();
-  return plhip::debug_read_fz_stamps(dst_host, bytes);
 }
 extern "C" int plhip_debug_read_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();

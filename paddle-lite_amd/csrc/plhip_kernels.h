@@ -148,7 +148,7 @@ struct DwArgs {
   unsigned ones = 0x01010101u;
 };
 
-// fused depthwise 3x3 (int8 out) -> pointwise 1x1
+// fused depthwise 3x3 (int8 out) -> pointwise 1x1 (fused_dwpw_i8.hip)
 struct FusedArgs {
   const int8_t* x;        // [n, C, h, w]
   const int8_t* dw_w;     // [C, 1, 3, 3]
@@ -157,13 +157,8 @@ struct FusedArgs {
   int dw_act;
   float dw_alpha;
   int n, C, h, w, oh, ow, pt, pl, stride;
-  // launch plan (fused_dwpw_plan): quads per output row, quads of the column space, the staged-input ring
-  int wn;                   // column groups (of 128) per workgroup: 8 / 4 / 2 / 1; WM = 8 / wn slices of 64 output channels
-  int owq;
-  long NQ;
-  int slot_bytes, ni, pwd;  // bytes / DMA instructions of one K-step of staged input, DMA instructions per wave
-  size_t raw_bytes;         // dynamic LDS (the LDS-DMA ring)
-  GemmArgs pw;              // wp, y, scale, bias, M, KS, HWY (= oh*ow), y_bstride, act, alpha
+  int tiles;              // launch plan (fused_dwpw_plan): (image, half-plane) tiles = 2 n
+  GemmArgs pw;            // wp, y, scale, bias, M, KS, HWY (= oh*ow), y_bstride, act, alpha
 };
 // fills the plan from (n, C, h, w, oh, ow, pt, pl, stride, pw.M); false = shape outside the fused path
 bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int dw, int out);

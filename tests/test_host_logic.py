@@ -149,10 +149,9 @@ def test_magic_division_is_exact_below_2_31():
 
 
 def test_fused_dwpw_support_query_is_host_only(pkg):
-    """plhip_dwpw_fused_supported is a pure function of the descriptors (no device): the stride-1 MobileNetV1 pairs fit the
-    fused path at batch 128 (the wide 56x56 tile narrows itself to fit the LDS), most stride-2 pairs do not (four K-steps
-    of their staged input rows exceed the LDS), 5x5 / dilated / non-depthwise convs never do, and an int8 output whose
-    OW % 4 == 1 (a compact output dword would span three quads) is refused while the fp32 one is taken."""
+    """plhip_dwpw_fused_supported is a pure function of the descriptors (no device): the fused kernel takes the 14 x 14
+    stride-1 pairs with 128 | C <= 512 and M = 256 / 512 (MobileNetV1's five 512 -> 512 pairs), every output kind; other
+    planes, strides, filters, channel counts are refused (the predictor then runs the two kernels)."""
     capi = pkg.capi
     lib = capi.load()
 
@@ -160,14 +159,10 @@ def test_fused_dwpw_support_query_is_host_only(pkg):
         d = capi.conv_desc(n, c, hw, hw, c, k, k, (k // 2,) * 4, (s, s), (dil, dil), c if groups is None else groups, capi.ACT_RELU, 0.0)
         return lib.plhip_dwpw_fused_supported(ctypes.byref(d), m, out)
 
-    if q(128, 512, 14, 1, 512) == 0:
-        # the default library carries no fused kernel (make EXPERIMENTS=1 builds it): the query must then refuse everything
-        for (c, hw, m) in [(32, 112, 64), (128, 56, 128), (256, 28, 256), (1024, 7, 1024)]:
-            assert q(128, c, hw, 1, m) == 0 and q(4, c, hw, 1, m, out=capi.OUT_F32) == 0, (c, hw, m)
-        return
-    for (c, hw, m) in [(32, 112, 64), (128, 56, 128), (256, 28, 256), (512, 14, 512), (1024, 7, 1024)]:
-        assert q(128, c, hw, 1, m) == 1, (c, hw, m)
-    assert q(128, 64, 112, 2, 128) == 0 and q(128, 512, 14, 2, 1024) == 0
+    for (c, m) in [(512, 512), (128, 256), (256, 512), (384, 256)]:
+        for out in (capi.OUT_I8, capi.OUT_F32, capi.OUT_I32):
+            assert q(128, c, 14, 1, m, out=out) == 1 and q(1, c, 14, 1, m, out=out) == 1, (c, m, out)
+    for (c, hw, m) in [(32, 112, 64), (128, 56, 128), (256, 28, 256), (1024, 7, 1024)]:
+        assert q(128, c, hw, 1, m) == 0, (c, hw, m)
+    assert q(128, 512, 14, 2, 1024) == 0 and q(128, 512, 14, 1, 1024) == 0 and q(128, 192, 14, 1, 256) == 0 and q(128, 640, 14, 1, 512) == 0
     assert q(128, 512, 14, 1, 512, k=5) == 0 and q(128, 512, 14, 1, 512, dil=2) == 0 and q(128, 512, 14, 1, 512, groups=1) == 0
-    assert q(4, 64, 13, 1, 64, out=capi.OUT_I8) == 0 and q(4, 64, 13, 1, 64, out=capi.OUT_F32) == 1
-    assert q(4, 2048, 14, 1, 64) == 0  # more channels than the parameter table holds
