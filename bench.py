@@ -158,7 +158,7 @@ class HipEngine:
                                0.0, float(o["in_scale"]), o["w_scale"], float(o["out_scale"]), True)
             self.out_var, self.plan = o["name"], None
         else:
-            wl.emit_graph(self.pred, net, rows, fuse_dwpw=os.environ.get("PLHIP_BENCH_FUSE_DWPW", "0") == "1")
+            wl.emit_graph(self.pred, net, rows, fuse_dwpw={"0": False, "1": True}.get(os.environ.get("PLHIP_BENCH_FUSE_DWPW", ""), None))
             self.plan = self.pred.graph_plan()
             self.pred.graph_lower()
             self.out_var = net["output"]
@@ -231,6 +231,30 @@ def build_net(wl, cfg, res):
     return dict(ops=[op], input="image", input_shape=(cin, 56, 56), output="y", shapes={"y": (cout, 56, 56)})
 
 
+def by_family(fam_out):
+    """Every kernel family of the step against both roofs (the `roofline` object is the one with the largest summed time)."""
+    out = {}
+    for k, f in (fam_out or {}).items():
+        if not f.get("ms"):
+            continue
+        out[k] = {"ms": f["ms"], "launches": f["launches"], "hbm_frac": round(f["GB/s"] / HBM_PEAK_GBS, 4),
+                  "mfma_frac": round(f["TOP/s"] / MFMA_I8_PEAK_TOPS, 4)}
+    return out
+
+
+def csrc_sha256():
+    """Hash of the kernel sources: `roofline.traffic` comes from a committed PMC pass and is only valid for the kernels that
+    pass measured (tools/pmc_traffic.py stores the same hash; there is no git on the GPU box)."""
+    import hashlib
+    d = os.path.join(ROOT, "paddle-lite_amd", "csrc")
+    hsh = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            hsh.update(f.encode())
+            hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def cpu_baseline(cfg, net, seconds):
     """The reference algorithm restated for the host (oracle/): im2col + int8 GEMM over (batch, group) for the dense convs
     (conv_impl.cc:490-598 structure), direct loops for depthwise, fused float epilogue, fp32 pool / add, OpenMP.
@@ -239,8 +263,9 @@ def cpu_baseline(cfg, net, seconds):
     from oracle import graph_oracle, plref
     rng = np.random.default_rng(99)
     c, h, w = net["input_shape"]
-    done, t0 = 0, time.perf_counter()
+    done, t0, per_pass = 0, time.perf_counter(), []
     while True:
+        tp = time.perf_counter()
         if cfg["model"] == "conv":
             o = net["ops"][0]
             x = rng.integers(-127, 128, (1, c, h, w)).astype(np.int8)
@@ -249,6 +274,7 @@ def cpu_baseline(cfg, net, seconds):
         else:
             graph_oracle.forward(plref, net, rng.uniform(-1, 1, (1, c, h, w)).astype(np.float32), keep=set(), via_gemm=True)
         done += 1
+        per_pass.append(time.perf_counter() - tp)
         el = time.perf_counter() - t0
         if el >= seconds or done >= 100000:
             break
@@ -262,6 +288,8 @@ def cpu_baseline(cfg, net, seconds):
         c1["note"] = ("MobileNetV1 fp32 1x3x%dx%d, oracle/x86_path.py: restatement of lite/kernels/x86/conv_compute.h:48-150 "
                       "(the reference's x86 build needs MKLML / gflags / protobuf downloads: unbuildable here)" % (h, w))
     return {"value": round(done / el, 2), "unit": "img/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+            "ms_per_image_min_avg_max": [round(1e3 * min(per_pass), 3), round(1e3 * sum(per_pass) / len(per_pass), 3), round(1e3 * max(per_pass), 3)],
+            "threads": int(os.environ["OMP_NUM_THREADS"]),
             "fp32_x86_path_ms": c1["avg_ms"] if c1 else None, "fp32_x86_path": c1,
             "sample": "%d images of the same graph, batch 1 each, %.1f s; oracle/ restatement of the reference's im2col+GEMM int8 "
                       "path (its ARM NEON kernels cannot run on x86; its x86 backend has no INT8 kernels)" % (done, el)}
@@ -563,6 +591,27 @@ def main():
                 else:
                     assert np.all(np.isfinite(blk)) and np.allclose(blk.sum(-1), 1.0, rtol=1e-3), "gathered probabilities are not distributions"
 
+        # ---- self-check, outside the timed region and BEFORE anything is re-run: what the last timed step of EVERY predictor
+        # left in its variables for the first two images of this rank's shard must equal the oracle's result for the same bytes
+        # (int8 tensors bit for bit, fp32 within the tolerance of the parity tests; predictor 0: every surviving variable, the
+        # others: the output); a mismatch makes the run fail instead of printing a rate for garbage
+        selfcheck = None
+        if details and rank == 0 and not dry and check_images is not None and not args.no_selfcheck:
+            selfcheck = oracle_selfcheck(np, engines[0].pred, net, cfg, check_images, engines[0].out_var)
+            others = []
+            for e_ in engines[1:]:
+                if e_ is None:
+                    continue
+                got = e_.pred.get_var(e_.out_var, np.int8 if cfg["model"] == "conv" else np.float32, max_bytes=1 << 30)[:check_images.shape[0]]
+                ref0 = engines[0].pred.get_var(engines[0].out_var, got.dtype, max_bytes=1 << 30)[:check_images.shape[0]]
+                others.append(bool(np.array_equal(got, ref0)))  # same program, same bytes in: identical to the verified predictor
+            selfcheck["predictors_checked"] = 1 + len(others)
+            selfcheck["ok"] = bool(selfcheck["ok"] and all(others))
+            if not selfcheck["ok"]:
+                sys.stderr.write("bench.py: SELF-CHECK FAILED: %s\n" % json.dumps(selfcheck))
+                real_stdout.flush()
+                os._exit(3)
+
         eng0 = engines[0]
         pred = None if dry else eng0.pred
         serial, roof, fam_out = None, None, {}
@@ -622,11 +671,9 @@ def main():
                     print("%-28s %-16s %8.4f ms  %7.1f GB/s %7.1f TOP/s  %s" % (
                         costs[i]["name"], costs[i]["family"], per_inst[i], costs[i]["bytes"] / per_inst[i] / 1e6,
                         costs[i]["ops"] / per_inst[i] / 1e9, names[i]), file=sys.stderr)
-            # the dominant family (pointwise keeps the label unless another one is clearly, > 10 %, larger: otherwise
-            # `roofline.kernel` would flip from run to run on MobileNetV1, where pointwise and depthwise are within a few %)
+            # the dominant family = the one with the largest summed launch time of a step, nothing else (families within a few
+            # per cent of each other may swap between runs: `roofline_by_family` in the line carries all of them)
             dom = max(fam_out, key=lambda k_: fam_out[k_]["ms"])
-            if "pointwise1x1" in fam_out and dom != "pointwise1x1" and fam_out[dom]["ms"] < 1.10 * fam_out["pointwise1x1"]["ms"]:
-                dom = "pointwise1x1"
             d = fam_out[dom]
             ai = d["ops"] / max(1, d["alg_bytes"])
             mfma_bound = ai > BALANCE_OPS_PER_BYTE
@@ -638,6 +685,8 @@ def main():
             if os.path.exists(tpath) and rows == cfg["batch"]:
                 try:
                     tj = json.load(open(tpath))
+                    if tj.get("csrc_sha256") != csrc_sha256():
+                        raise ValueError("kernel sources changed since the PMC pass")
                     t_ = tj.get(dom)
                     if not t_ and dom == "conv3x3" and "conv3x3_patch" in tj:  # one conv = the padded copy + the patch kernel
                         t_ = {k_: tj["conv3x3_patch"][k_] + tj.get("conv3x3_patch_pad", {}).get(k_, 0.0)
@@ -645,8 +694,8 @@ def main():
                     if t_:
                         traffic = round(t_["fetch_bytes_per_launch_x2"] + t_["write_bytes_per_launch"])
                         tsrc = "profiles/%s @ %s (not measured in this run)" % (os.path.basename(tpath), tj.get("commit", "round 1"))
-                except Exception:  # noqa: BLE001
-                    traffic = None
+                except Exception as e_:  # noqa: BLE001
+                    traffic, tsrc = None, "profiles/%s refused: %s" % (os.path.basename(tpath), e_)
             roof = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm",
                     "achieved": d["TOP/s"] if mfma_bound else d["GB/s"], "peak": round(MFMA_I8_PEAK_TOPS, 1) if mfma_bound else HBM_PEAK_GBS,
                     "unit": "TOP/s" if mfma_bound else "GB/s",
@@ -659,17 +708,6 @@ def main():
                     "note": "family aggregate: algorithmic bytes = unique input + weights + output once per launch (SURVEY.md 8d), "
                             "summed over the family's launches of one step, / summed launch time (HIP events on the launch "
                             "stream, 4 launches per event pair); bound = mfma iff ops/byte > %.0f" % BALANCE_OPS_PER_BYTE}
-
-        # ---- self-check, outside the timed region: what the timed program computed for the first two images of this rank's
-        # shard must equal the oracle's result for the same bytes (int8 tensors bit for bit, fp32 within the tolerance of the
-        # parity tests); a mismatch makes the run fail instead of printing a rate for garbage
-        selfcheck = None
-        if details and rank == 0 and not dry and check_images is not None and not args.no_selfcheck:
-            selfcheck = oracle_selfcheck(np, pred, net, cfg, check_images, eng0.out_var)
-            if not selfcheck["ok"]:
-                sys.stderr.write("bench.py: SELF-CHECK FAILED: %s\n" % json.dumps(selfcheck))
-                real_stdout.flush()
-                os._exit(3)
 
         cpu = None
         if details and rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
@@ -720,7 +758,7 @@ def main():
                         "ms_per_step_min_median_max": [round(1e3 * min(wins) / args.steps, 4), round(1e3 * elapsed / args.steps, 4),
                                                        round(1e3 * max(wins) / args.steps, 4)]},
             "selfcheck": selfcheck, "strong": strong,
-            "single_stream": serial, "roofline": roof, "kernels": fam_out, "cpu_baseline": cpu,
+            "single_stream": serial, "roofline": roof, "roofline_by_family": by_family(fam_out), "kernels": fam_out, "cpu_baseline": cpu,
         }
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()

@@ -206,6 +206,13 @@ plhip_status plhip_elementwise_add_f32(plhip_ctx* ctx, const float* x, const flo
  * Runs a tiny known-answer GEMM through the MFMA path; returns PLHIP_OK iff bit-exact. ---- */
 plhip_status plhip_selftest(plhip_ctx* ctx);
 
+/* ---- diagnostics (no effect on results): switches of the shipped library are set HERE, never through the environment,
+ * so that a stray variable cannot change which kernel a benchmark measures.  key: "fused_stamps" (1 = the fused
+ * depthwise -> pointwise kernel records its in-kernel timeline, read back with plhip_debug_read_fw_stamps:
+ * [tile][wave][16] shader-clock stamps).  Returns 0, or -1 for an unknown key. ---- */
+int plhip_debug_set(const char* key, int value);
+int plhip_debug_read_fw_stamps(void* dst_host, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

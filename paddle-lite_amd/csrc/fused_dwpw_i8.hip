@@ -38,18 +38,39 @@ constexpr int FW_NT = 4;       // 32-pixel n tiles per tile (2 rows of pitch 16 
 constexpr int FW_SP = 112;     // staging pitch of a channel row (98 bytes used)
 constexpr int FW_KSTEP = 4096; // LDS bytes of one K-step of the activation image: [kg 4][k%8 8][chunk slot 8][16 B]
 
-// 8 bytes of an input row from byte offset `off` (>= 0) of the tensor
-__device__ __forceinline__ void fw_load_row(const int8_t* __restrict__ xs, int off, uint32_t (&d)[2]) {
-  __builtin_memcpy(d, xs + (uint32_t)off, 8);
+// ---- diagnostic timeline (plhip_debug_set("fused_stamps", 1); never set in production): s_memtime per wave at the phase
+// boundaries, read back by plhip_debug_read_fw_stamps (tools/fused_timeline.py).  Slots: 0 realtime start, 1 entry, 2 operands
+// of round 0 requested, 3 round 0 produced, 4 + 2 (r - 1) round r done, 5 + 2 (r - 1) behind its barrier (r < 5), 12 last
+// K-steps multiplied, 13 requantised + staged, 14 stores issued, 15 stores acknowledged
+constexpr int FW_STAMP_SLOTS = 16;
+__device__ unsigned long long g_fw_stamps[1024 * 8 * FW_STAMP_SLOTS];
+static int g_fw_debug = 0;
+void debug_set_fused(int v) { g_fw_debug = v; }  // bit 5: stamps; bits 0-1: timing experiments
+int debug_read_fw_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(g_fw_stamps)) bytes = sizeof(g_fw_stamps);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fw_stamps), bytes) == hipSuccess ? 0 : -1;
+}
+#define PLHIP_FW_STAMP(i)                                                                                   \
+  do {                                                                                                      \
+    if (diag && lane == 0) g_fw_stamps[((size_t)vb * 8 + wave) * FW_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+// 8 bytes of an input row: scalar base + the lane's 32-bit offset (>= 0) + a compile-time row distance (the immediate of
+// the load: no address arithmetic per row)
+template <int DELTA>
+__device__ __forceinline__ void fw_load_row(const int8_t* __restrict__ xs, uint32_t off, uint32_t (&d)[2]) {
+  __builtin_memcpy(d, xs + off + DELTA, 8);
 }
 
 // MTW: 32-row m tiles per wave (M = 256 MTW).  OUT: output kind.  DWNN / PWNN: the depthwise / pointwise activation is
 // relu or relu6 (the packed non-negative requantisation); else none / leaky (leaky with slope 1 for none: exact).
-template <int MTW, int OUT, bool DWNN, bool PWNN>
+// EXP (timing experiments only, results are wrong): 1 = no MFMAs in the produce + consume rounds, 2 = no depthwise arithmetic there
+template <int MTW, int OUT, bool DWNN, bool PWNN, int EXP = 0, int SPLIT = 0, int NEWQ = 1>
 __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   const GemmArgs& g = a.pw;
   PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.dw_w); PLHIP_PRELOAD(a.dw_scale); PLHIP_PRELOAD(a.dw_bias); PLHIP_PRELOAD(a.dw_act);
-  PLHIP_PRELOAD(a.dw_alpha); PLHIP_PRELOAD(a.n); PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.tiles); PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.y);
+  PLHIP_PRELOAD(a.dw_alpha); PLHIP_PRELOAD(a.n); PLHIP_PRELOAD(a.C); PLHIP_PRELOAD(a.tiles); PLHIP_PRELOAD(a.ones); PLHIP_PRELOAD(g.wp); PLHIP_PRELOAD(g.y);
   PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias); PLHIP_PRELOAD(g.M); PLHIP_PRELOAD(g.KS); PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha);
   extern __shared__ __attribute__((aligned(16))) uint8_t fw_lds[];  // [activation image KS x 4096][8 waves x 32 MTW rows x FW_SP]
   const int lane = threadIdx.x & 63;
@@ -59,6 +80,17 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   const unsigned vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (vb >= nb) return;  // block-uniform
   const int b = (int)(vb >> 1), hf = (int)(vb & 1);
+  const bool diag = (g.dbg & 32) != 0 && vb < 1024;
+#ifdef PLHIP_FW_AGPR
+  // accumulators in AGPRs (this file is built WITHOUT -amdgpu-mfma-vgpr-form): naming one AGPR makes the compiler keep the
+  // accumulator file for the MFMA results, whose reads / writes then do not compete with the VALU for the VGPR ports
+  {
+    int agpr_hint;
+    asm volatile("; keep AGPRs %0" : "=a"(agpr_hint));
+  }
+#endif
+  if (diag && lane == 0) g_fw_stamps[((size_t)vb * 8 + wave) * FW_STAMP_SLOTS] = __builtin_amdgcn_s_memrealtime();
+  PLHIP_FW_STAMP(1);
   const int KS = g.KS, C = a.C, R = KS >> 2;  // rounds of 128 channels (K % 128 == 0: fused_dwpw_plan)
   const int c = lane & 31, h = lane >> 5;
 
@@ -71,11 +103,13 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   // and meet a zeroed filter row.
   const uint32_t sel_lo = q == 0 ? 0x0201000cu : (q == 1 ? 0x03020100u : (q == 2 ? 0x04030201u : 0x0c070605u));
   const uint32_t sel_hi = q == 0 ? 0x06050403u : (q == 1 ? 0x07060504u : (q == 2 ? 0x0c070605u : 0x0c0c0c0cu));
-  // byte offset of (image b, channel 16 wave + chl, input row 7 hf - 1, the window's fetch column); a round advances it by
-  // 128 planes.  (Negative only for the first plane's row -1, which is never fetched.)
-  int xoff = ((b * C + 16 * wave + chl) * 14 + 7 * hf - 1) * 14 + (q == 0 ? 0 : (q == 1 ? 3 : 6));
+  // byte offset of (image b, channel 16 wave + chl, input row 7 hf, the window's fetch column); a round advances it by 128
+  // planes.  Strip row t is input row 7 hf - 1 + t: distance 14 (t - 1), an immediate; the two rows that can lie outside
+  // the image get their own scalar base (the neighbouring row's address).
+  uint32_t xoff = (uint32_t)(((b * C + 16 * wave + chl) * 14 + 7 * hf) * 14 + (q == 0 ? 0 : (q == 1 ? 3 : 6)));
   const uint32_t top = hf == 0 ? 0u : 0xffffffffu, bot = hf == 1 ? 0u : 0xffffffffu;  // scalar (block-uniform)
-  const int d0 = hf == 0 ? 14 : 0, d8 = hf == 1 ? 98 : 112;                            // row offsets of t = 0 / t = 8
+  const int8_t* const xs0 = a.x + (hf == 0 ? 0 : -14);   // strip row 0: input row 7 hf - 1, or row 0 again for the upper half
+  const int8_t* const xs8 = a.x + (hf == 1 ? 84 : 98);   // strip row 8: input row 7 hf + 7, or row 13 again for the lower half
   // activation image address of (channel, output row o, quad): k = channel: K-step k / 32, kg = (k % 32) / 8, row k % 8,
   // chunk o in slot o ^ (2 ((k % 8) >> 1)) (the swizzle of gemm_wide_kernel.h), byte 4 q:  address = wbase ^ (o << 4)
   const int ch0 = 16 * wave + chl;
@@ -86,7 +120,13 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   uint32_t in[9][2];   // the 9 input row windows of the task being produced / fetched
   uint32_t wr[3];      // its packed filter rows (w0, w1, w2, 0)
   float dsc, dbi;      // its doubled scale / bias
-  auto fetch_task = [&](int ch, int off) __attribute__((always_inline)) {
+  auto load_row = [&](auto t_c, uint32_t off, uint32_t (&d)[2]) __attribute__((always_inline)) {
+    constexpr int t = decltype(t_c)::value;
+    if constexpr (t == 0) fw_load_row<0>(xs0, off, d);
+    else if constexpr (t == 8) fw_load_row<0>(xs8, off, d);
+    else fw_load_row<14 * (t - 1)>(a.x, off, d);
+  };
+  auto fetch_task = [&](int ch, uint32_t off) __attribute__((always_inline)) {
     // ch / off: this lane's channel and window offset of the task
     const int8_t* wp = a.dw_w + (size_t)ch * 9;
     uint32_t w0, w1, w2;
@@ -99,8 +139,15 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
     const float s = a.dw_scale[ch], bb = a.dw_bias ? a.dw_bias[ch] : 0.f;
     dsc = s + s;
     dbi = bb + bb;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) fw_load_row(a.x, off + (t == 0 ? d0 : (t == 8 ? d8 : 14 * t)), in[t]);
+    load_row(std::integral_constant<int, 0>{}, off, in[0]);
+    load_row(std::integral_constant<int, 1>{}, off, in[1]);
+    load_row(std::integral_constant<int, 2>{}, off, in[2]);
+    load_row(std::integral_constant<int, 3>{}, off, in[3]);
+    load_row(std::integral_constant<int, 4>{}, off, in[4]);
+    load_row(std::integral_constant<int, 5>{}, off, in[5]);
+    load_row(std::integral_constant<int, 6>{}, off, in[6]);
+    load_row(std::integral_constant<int, 7>{}, off, in[7]);
+    load_row(std::integral_constant<int, 8>{}, off, in[8]);
   };
 
   // ------------------------------------------------------------------ consumer state
@@ -113,11 +160,12 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
     tr00 = (uint32_t)((h * 2) * 1024 + qr * 128 + ((2 * (qr >> 1) + par) * 16) + (lane & 1) * 8);
   }
   const int mt0 = wave * MTW;  // my first 32-row m tile
-  const uint8_t* wpk = reinterpret_cast<const uint8_t*>(g.wp) + (size_t)mt0 * KS * 1024 + lane * 16;  // [mt][ks][64 lanes][16 B]
+  const uint8_t* const wpk = reinterpret_cast<const uint8_t*>(g.wp) + (size_t)mt0 * KS * 1024;  // [mt][ks][64 lanes][16 B]: wave-uniform
+  const uint32_t wlane = (uint32_t)lane * 16;
   v4i W[4][MTW];       // weight fragments of the 4 K-steps being multiplied / fetched
   auto fetch_w = [&](int j, int ks) __attribute__((always_inline)) {
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) W[j][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS + ks) * 1024);
+    for (int m = 0; m < MTW; ++m) W[j][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS + ks) * 1024 + wlane);  // scalar base + lane offset
   };
   v16i acc[FW_NT][MTW];
 #pragma unroll
@@ -132,11 +180,17 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   // into the same registers behind their last use.  CONSUME: K-steps 4 rc .. 4 rc + 3 (W) multiplied, the next four fetched.
   // The MFMAs are dealt over the 9 row chunks of the task so that every chunk carries VALU and matrix work side by side.
   using std::integral_constant;
-  auto round = [&](auto produce_c, auto consume_c, int rp, int rc) __attribute__((always_inline)) {
+  // ORDER (produce + consume rounds): 0 = the MFMAs dealt over the 9 row chunks; 1 = all MFMAs, then the task; 2 = the task,
+  // then all MFMAs.  The two waves of a SIMD (w and w + 4) run the same code in step behind each barrier: with order 0 both
+  // reach their MFMAs together and their VALU bursts together.  Orders 1 / 2 on the two halves of the block put one wave's
+  // matrix burst beside the other's depthwise arithmetic.
+  auto round = [&](auto produce_c, auto consume_c, auto order_c, int rp, int rc) __attribute__((always_inline)) {
     constexpr bool PRODUCE = decltype(produce_c)::value, CONSUME = decltype(consume_c)::value;
+    constexpr int ORDER = decltype(order_c)::value;
     // next task (clamped: the last round fetches its own operands again, unused)
     const int rn = rp + 1 < R ? rp + 1 : rp;
-    const int nch = 128 * rn + 16 * wave + chl, noff = xoff + (rn - rp) * 128 * 196;
+    const int nch = 128 * rn + 16 * wave + chl;
+    const uint32_t noff = xoff + (uint32_t)(rn - rp) * (128 * 196);
     const uint32_t wb = wbase + (uint32_t)rp * (4 * FW_KSTEP);
     const uint32_t rb = (uint32_t)rc * (4 * FW_KSTEP);
     int dacc[FW_TR][4];
@@ -184,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
     };
     auto chunk = [&](auto t_c) __attribute__((always_inline)) {
       constexpr int t = decltype(t_c)::value;
-      if constexpr (CONSUME) mfmas(mfmas, integral_constant<int, mstart(t)>{}, integral_constant<int, mstart(t + 1)>{});
-      if constexpr (PRODUCE) {
+      if constexpr (CONSUME && !(EXP == 1 && PRODUCE) && ORDER == 0) mfmas(mfmas, integral_constant<int, mstart(t)>{}, integral_constant<int, mstart(t + 1)>{});
+      if constexpr (PRODUCE && !(EXP == 2 && CONSUME)) {
         const uint32_t e0 = __builtin_amdgcn_perm(in[t][1], in[t][0], sel_lo), e1 = __builtin_amdgcn_perm(in[t][1], in[t][0], sel_hi);
         uint32_t win[4];
         win[0] = e0;
@@ -202,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
                                  : __builtin_amdgcn_sdot4((int)win[jj], (int)(t == 8 ? wr2b : wr[r]), dacc[o][jj], false);
         }
         // the next task's row t into the registers just consumed
-        fw_load_row(a.x, noff + (t == 0 ? d0 : (t == 8 ? d8 : 14 * t)), in[t]);
+        load_row(integral_constant<int, t>{}, noff, in[t]);
         if constexpr (t == 2) {
           const int8_t* wp = a.dw_w + (size_t)nch * 9;
           uint32_t w0, w1, w2;
@@ -213,17 +267,22 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
           nwr[1] = w1 & 0xffffffu;
           nwr[2] = w2 >> 8;
           ndsc = a.dw_scale[nch];
-          ndbi = a.dw_bias ? a.dw_bias[nch] : 0.f;
+          ndbi = (a.dw_bias ? a.dw_bias : a.dw_scale)[nch];  // no branch inside the round
+          if (!a.dw_bias) ndbi = 0.f;
         }
         if constexpr (t >= 2) {  // output row t - 2 is complete
           constexpr int o = t - 2;
-          const uint32_t pk = DWNN ? dw_requant4<ACT_RELU6>(dacc[o], dsc, dbi, 0.f, 0.f, dw_hi2)
+          const uint32_t pk = DWNN ? (NEWQ ? requant4_nn_rtz(dacc[o], dsc, dbi, dw_hi2, a.ones) : dw_requant4<ACT_RELU6>(dacc[o], dsc, dbi, 0.f, 0.f, dw_hi2, a.ones))
                                    : dw_requant4<ACT_LEAKY>(dacc[o], dsc, dbi, dw_leak, -254.f, 254.f);
           *reinterpret_cast<uint32_t*>(fw_lds + (wb ^ (uint32_t)(o << 4))) = pk;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
+    if constexpr (CONSUME && ORDER == 1 && !(EXP == 1 && PRODUCE)) {
+      mfmas(mfmas, integral_constant<int, 0>{}, integral_constant<int, NM>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
     chunk(integral_constant<int, 0>{});
     chunk(integral_constant<int, 1>{});
     chunk(integral_constant<int, 2>{});
@@ -233,7 +292,8 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
     chunk(integral_constant<int, 6>{});
     chunk(integral_constant<int, 7>{});
     chunk(integral_constant<int, 8>{});
-    if constexpr (PRODUCE) {
+    if constexpr (CONSUME && ORDER == 2 && !(EXP == 1 && PRODUCE)) mfmas(mfmas, integral_constant<int, 0>{}, integral_constant<int, NM>{});
+    if constexpr (PRODUCE && !(EXP == 2 && CONSUME)) {
       wr[0] = nwr[0];
       wr[1] = nwr[1];
       wr[2] = nwr[2];
@@ -247,13 +307,20 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   fetch_w(1, 1 < KS ? 1 : KS - 1);
   fetch_w(2, 2 < KS ? 2 : KS - 1);
   fetch_w(3, 3 < KS ? 3 : KS - 1);
-  round(std::true_type{}, std::false_type{}, 0, 0);
+  PLHIP_FW_STAMP(2);
+  using O0 = integral_constant<int, 0>;
+  round(std::true_type{}, std::false_type{}, O0{}, 0, 0);
   xoff += (R > 1 ? 1 : 0) * 128 * 196;
+  PLHIP_FW_STAMP(3);
   __syncthreads();
   for (int r = 1; r < R; ++r) {
-    round(std::true_type{}, std::true_type{}, r, r - 1);
+    if (SPLIT == 0) round(std::true_type{}, std::true_type{}, O0{}, r, r - 1);
+    else if (wave < 4) round(std::true_type{}, std::true_type{}, integral_constant<int, 1>{}, r, r - 1);
+    else round(std::true_type{}, std::true_type{}, integral_constant<int, 2>{}, r, r - 1);
     xoff += (r + 1 < R ? 1 : 0) * 128 * 196;
+    if (r < 5) PLHIP_FW_STAMP(4 + 2 * (r - 1));
     __syncthreads();
+    if (r < 5) PLHIP_FW_STAMP(5 + 2 * (r - 1));
   }
   float psc[MTW], pbi[MTW];  // pointwise scale / bias of this lane's channels: fetched under the last round's MFMAs
 #pragma unroll
@@ -265,7 +332,8 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
       if (g.bias) pbi[m] = g.bias[(mt0 + m) * 32 + c];
     }
   }
-  round(std::false_type{}, std::true_type{}, R, R - 1);
+  round(std::false_type{}, std::true_type{}, O0{}, R, R - 1);
+  PLHIP_FW_STAMP(12);
 
   // ------------------------------------------------------------------ epilogue
   // accumulator register r of n tile n: pixel 32 n + 8 (r >> 2) + 4 h + (r & 3) = output row 2 n + (r >> 3), column
@@ -285,7 +353,8 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
         for (int gq = 0; gq < 4; ++gq) {
           if (n == FW_NT - 1 && gq >= 2) continue;  // row 7 of the tile does not exist
           int v[4] = {acc[n][m][4 * gq], acc[n][m][4 * gq + 1], acc[n][m][4 * gq + 2], acc[n][m][4 * gq + 3]};
-          edw[gq] = PWNN ? dw_requant4<ACT_RELU6>(v, s2, b2, 0.f, 0.f, hi2) : dw_requant4<ACT_LEAKY>(v, s2, b2, leak, -254.f, 254.f);
+          edw[gq] = PWNN ? (NEWQ ? requant4_nn_rtz(v, s2, b2, hi2, a.ones) : dw_requant4<ACT_RELU6>(v, s2, b2, 0.f, 0.f, hi2, a.ones))
+                         : dw_requant4<ACT_LEAKY>(v, s2, b2, leak, -254.f, 254.f);
         }
         // half exchange: every lane gets the 16 pixels of ONE output row of its channel (h = 0: row 2 n, h = 1: row 2 n + 1)
         auto s02 = __builtin_amdgcn_permlane32_swap(edw[0], edw[2], false, false);
@@ -301,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
         }
       }
     }
+    PLHIP_FW_STAMP(13);
     // copy-out: lane -> (row lane >> 3 of a group of 8, 16-byte piece lane & 7); a channel row is 98 contiguous bytes
     const int piece = lane & 7, rsub = lane >> 3;
     int8_t* ybase = reinterpret_cast<int8_t*>(g.y) + ((size_t)b * g.M + mt0 * 32) * 196 + 98 * hf + piece * 16;
@@ -359,6 +429,11 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
       }
     }
   }
+  PLHIP_FW_STAMP(14);
+  if (diag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PLHIP_FW_STAMP(15);
+  }
 }
 
 // Fills the launch plan and says whether the shape is inside the fused path: 3x3, stride 1, dilation 1, pad 1 on a 14 x 14
@@ -372,6 +447,7 @@ bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int d
   if (a->n < 1 || (long)a->n * a->C * 196 >= ((long)1 << 31) - 65536 || (long)a->n * a->pw.M * 196 >= ((long)1 << 31)) return false;
   (void)out;
   a->tiles = 2 * a->n;
+  a->ones = 0x01010101u;
   return true;
 }
 
@@ -387,6 +463,34 @@ static void launch_fused_t(const FusedArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);                                                 \
   } while (0)
+  if (OUT == OUT_I8 && MTW == 2 && dwnn && pwnn && (a.pw.dbg & 12)) {
+    if ((a.pw.dbg & 12) == 4) {
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 1, 1>;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    } else if ((a.pw.dbg & 12) == 8) {
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 0, 0>;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    } else {
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 1, 0>;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    }
+    return;
+  }
+  if (OUT == OUT_I8 && MTW == 2 && dwnn && pwnn && (a.pw.dbg & 3)) {  // timing experiments (plhip_debug_set("fused_exp", 1 | 2))
+    if (a.pw.dbg & 1) {
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 1>;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    } else {
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 2>;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    }
+    return;
+  }
   if (OUT == OUT_I8) {
     if (dwnn && pwnn) PLHIP_FW_LAUNCH(true, true);
     else if (dwnn) PLHIP_FW_LAUNCH(true, false);
@@ -400,7 +504,9 @@ static void launch_fused_t(const FusedArgs& a, hipStream_t s) {
 }
 
 // `a` must have passed fused_dwpw_plan with the same `out`.
-void launch_fused_dwpw(const FusedArgs& a, int out, hipStream_t s) {
+void launch_fused_dwpw(const FusedArgs& a_in, int out, hipStream_t s) {
+  FusedArgs a = a_in;
+  a.pw.dbg = g_fw_debug;
   if (a.pw.M == 512) {
     if (out == OUT_I32) launch_fused_t<2, OUT_I32>(a, s);
     else if (out == OUT_F32) launch_fused_t<2, OUT_F32>(a, s);

@@ -899,6 +899,19 @@ extern "C" int plhip_debug_read_tr_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();
   return plhip::debug_read_tr_stamps(dst_host, bytes);
 }
+extern "C" int plhip_debug_read_fw_stamps(void* dst_host, size_t bytes) {
+  if (!dst_host) return -1;
+  return plhip::debug_read_fw_stamps(dst_host, bytes);
+}
+// Diagnostics switch of the shipped library (not part of the operator ABI; declared in include/plhip.h so that nothing in
+// the library's behaviour depends on the environment): key = "fused_stamps" -> in-kernel timeline of the fused kernel
+extern "C" int plhip_debug_set(const char* key, int value) {
+  if (!key) return -1;
+  static int fused_bits = 0;
+  if (!strcmp(key, "fused_stamps")) { fused_bits = (fused_bits & ~32) | (value ? 32 : 0); plhip::debug_set_fused(fused_bits); return 0; }
+  if (!strcmp(key, "fused_exp")) { fused_bits = (fused_bits & ~15) | (value & 15); plhip::debug_set_fused(fused_bits); return 0; }  // timing experiments, wrong results
+  return -1;
+}
 extern "C" int plhip_debug_read_stamps(void* dst_host, size_t bytes) {
   (void)hipDeviceSynchronize();
   return plhip::debug_read_stamps(dst_host, bytes);

@@ -158,11 +158,14 @@ struct FusedArgs {
   float dw_alpha;
   int n, C, h, w, oh, ow, pt, pl, stride;
   int tiles;              // launch plan (fused_dwpw_plan): (image, half-plane) tiles = 2 n
+  unsigned ones;          // 0x01010101 as a scalar operand (the byte-wise +1 of the packed rounding)
   GemmArgs pw;            // wp, y, scale, bias, M, KS, HWY (= oh*ow), y_bstride, act, alpha
 };
 // fills the plan from (n, C, h, w, oh, ow, pt, pl, stride, pw.M); false = shape outside the fused path
 bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int dw, int out);
 void launch_fused_dwpw(const FusedArgs& a, int out, hipStream_t s);
+void debug_set_fused(int v);                        // bit 5 (32): timeline stamps
+int debug_read_fw_stamps(void* dst, size_t bytes);
 
 void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);
 // second-generation ring kernel (gemm_tr_i8.hip); false = shape outside it, the caller falls back

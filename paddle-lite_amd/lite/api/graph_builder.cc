@@ -1,6 +1,10 @@
 // graph_builder.cc — see graph_builder.h.
 #include "lite/api/graph_builder.h"
 
+#include <string.h>
+
+#include "plhip.h"
+
 #include <cstdio>
 #include <set>
 
@@ -180,7 +184,38 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
     dead[i] = true;
     st[pc].drop_f32 = uses(st[pc].out) == 0;
   }
-  // (D) opt-in: depthwise_conv2d[int8_out] whose only consumer is a plain 1x1 conv (no tail of its own) takes it over
+  // (D) depthwise_conv2d[int8_out] whose only consumer is a plain 1x1 conv (no tail of its own) takes it over.  Mode 2 (default):
+  // only where the fused kernel takes the pair, which needs the depthwise conv's input shape: propagated from the feeds through
+  // conv / calib / elementwise ops (anything else: shape unknown, no fusion)
+  std::map<std::string, std::vector<int64_t>> shape;
+  if (fuse_dwpw_ == 2) {
+    for (auto& f : feeds_) shape[f.name] = f.dims;
+    for (size_t i = 0; i < st.size(); ++i) {
+      if (dead[i]) continue;
+      if (st[i].kind != "op") {  // io_copy / calib: same shape
+        auto it = shape.find(st[i].in);
+        if (it != shape.end()) shape[st[i].out] = it->second;
+        continue;
+      }
+      const GraphOp& op = ops_[st[i].op];
+      if (st[i].op_inputs.empty()) continue;
+      auto it = shape.find(st[i].op_inputs[0]);
+      if (it == shape.end() || it->second.size() != 4) continue;
+      const std::vector<int64_t> in = it->second;
+      std::vector<int64_t> o;
+      if ((op.type == "conv2d" || op.type == "depthwise_conv2d") && op.w_dims.size() == 4 && op.conv.paddings.size() == 4 &&
+          op.conv.strides.size() == 2 && op.conv.dilations.size() == 2) {
+        const int64_t keh = op.conv.dilations[0] * (op.w_dims[2] - 1) + 1, kew = op.conv.dilations[1] * (op.w_dims[3] - 1) + 1;
+        o = {in[0], op.w_dims[0], (in[2] + op.conv.paddings[0] + op.conv.paddings[1] - keh) / op.conv.strides[0] + 1,
+             (in[3] + op.conv.paddings[2] + op.conv.paddings[3] - kew) / op.conv.strides[1] + 1};
+      } else if (op.type == "elementwise_add" || op.type == "fusion_elementwise_add_activation") {
+        o = in;
+      }
+      if (o.empty()) continue;
+      shape[st[i].out] = o;
+      if (!st[i].calib_out.empty()) shape[st[i].calib_out] = o;
+    }
+  }
   if (fuse_dwpw_) {
     for (size_t i = 0; i < st.size(); ++i) {
       if (dead[i] || st[i].kind != "op" || ops_[st[i].op].type != "depthwise_conv2d" || !st[i].int8_out || st[i].pw_op >= 0) continue;
@@ -200,6 +235,21 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
       bool pad0 = true;
       for (int v : c.conv.paddings) pad0 = pad0 && v == 0;
       if (!pad0 || !st[j].res.empty() || !st[j].calib_out.empty() || st[j].drop_f32) continue;
+      if (fuse_dwpw_ == 2) {
+        const GraphOp& dwo = ops_[st[i].op];
+        auto it = st[i].op_inputs.empty() ? shape.end() : shape.find(st[i].op_inputs[0]);
+        if (it == shape.end() || it->second.size() != 4 || dwo.conv.paddings.size() != 4) continue;
+        plhip_conv_desc d;
+        memset(&d, 0, sizeof(d));
+        d.n = static_cast<int>(it->second[0]); d.cin = static_cast<int>(it->second[1]);
+        d.h = static_cast<int>(it->second[2]); d.w = static_cast<int>(it->second[3]);
+        d.cout = static_cast<int>(dwo.w_dims[0]); d.kh = static_cast<int>(dwo.w_dims[2]); d.kw = static_cast<int>(dwo.w_dims[3]);
+        for (int q = 0; q < 4; ++q) d.pad[q] = dwo.conv.paddings[q];
+        d.stride[0] = dwo.conv.strides[0]; d.stride[1] = dwo.conv.strides[1];
+        d.dil[0] = dwo.conv.dilations[0]; d.dil[1] = dwo.conv.dilations[1];
+        d.groups = dwo.conv.groups;
+        if (!plhip_dwpw_fused_supported(&d, static_cast<int>(c.w_dims[0]), st[j].int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32)) continue;
+      }
       st[i].pw_op = st[j].op;
       st[i].pw_int8_out = st[j].int8_out;
       st[i].pw_out_scale = st[j].out_scale;

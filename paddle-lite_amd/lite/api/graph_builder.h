@@ -53,9 +53,12 @@ class GraphBuilder {
   //   conv2d[fp32_out] -> elementwise_add | fusion_elementwise_add_activation(relu) -> calib   => ONE conv launch
   //   conv2d[fp32_out] -> pool2d(max) -> calib                                  => conv + fused calib, int8 max pool
   void set_fuse(bool on) { fuse_ = on; }
-  // Opt-in (off by default: the fused kernel is exact but, measured, not faster than the two kernels — DESIGN.md 8):
   //   depthwise_conv2d[int8_out] -> conv2d 1x1 (stride 1, no padding, groups 1, no fused tail), sole consumer  => ONE instruction
-  void set_fuse_dwpw(bool on) { fuse_dwpw_ = on; }
+  // Default (mode 2): only the pairs the fused kernel takes (plhip_dwpw_fused_supported on the shapes propagated from the
+  // feeds: one launch, the int8 tensor between the two convs never leaves the CU — DESIGN.md 8); set_fuse_dwpw(true) = mode 1
+  // takes every eligible pair over (shapes outside the kernel run as two launches inside the one instruction), false = off.
+  void set_fuse_dwpw(bool on) { fuse_dwpw_ = on ? 1 : 0; }
+  void set_fuse_dwpw_mode(int mode) { fuse_dwpw_ = mode; }
   GraphOp& Add(const std::string& type, const std::vector<std::string>& inputs, const std::string& output);
   // Emits the program into `pred`; returns the host-side names of the fetched variables ("<name>/host").
   std::vector<std::string> Lower(HipPredictor* pred);
@@ -93,7 +96,7 @@ class GraphBuilder {
     PrecisionType prec;
   };
   bool fuse_{true};
-  bool fuse_dwpw_{false};
+  int fuse_dwpw_{2};
   std::vector<FeedDesc> feeds_;
   std::vector<std::string> fetches_;
   std::vector<GraphOp> ops_;

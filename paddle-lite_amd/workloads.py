@@ -270,12 +270,15 @@ def net_stats(net):
     return macs
 
 
-def emit_graph(pred, net, batch, fuse=True, fuse_dwpw=False):
+def emit_graph(pred, net, batch, fuse=True, fuse_dwpw=None):
     """Feed the op list to the predictor's graph mode and lower it.  Returns the host name of the output variable.
-    fuse=False: the reference program instruction for instruction (no kHIP graph-level fusion)."""
+    fuse=False: the reference program instruction for instruction (no kHIP graph-level fusion).
+    fuse_dwpw: None = the builder's default (depthwise -> pointwise pairs the fused kernel takes become one instruction),
+    True = every eligible pair (shapes outside the kernel run as two launches inside the instruction), False = none."""
     from . import liteapi
     pred.graph_set_fuse(fuse)
-    pred.graph_set_fuse_dwpw(fuse_dwpw)
+    if fuse_dwpw is not None:
+        pred.graph_set_fuse_dwpw(fuse_dwpw)
     c, h, w = net["input_shape"]
     pred.graph_feed(net["input"], (batch, c, h, w), liteapi.PREC_FLOAT)
     for o in net["ops"]:

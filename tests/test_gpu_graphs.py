@@ -102,7 +102,7 @@ def test_fc_kernel_classes_pick_the_reference_route(lite, plref):
         assert np.array_equal(y, ref), (ws.size, int8_out)
 
 
-def _run_graph(lite, wl, net, img, fuse=False, fuse_dwpw=False):
+def _run_graph(lite, wl, net, img, fuse=False, fuse_dwpw=None):
     p = lite.Predictor(0)
     try:
         out = wl.emit_graph(p, net, img.shape[0], fuse=fuse, fuse_dwpw=fuse_dwpw)
@@ -414,26 +414,26 @@ def test_int8_max_pool_commutes_with_calib(gpu_ctx, plref):
         assert np.array_equal(gpu_ctx.pool2d(xi, "max", (k, k), (s, s), pads), want)
 
 
-@pytest.mark.parametrize("which,batch", [("mobilenet_v1", 2), ("mobilenet_v1", 9), ("mobilenet_v2", 3)])
-def test_opt_in_dwpw_fusion_equals_the_oracle_graph(lite, wl, plref, which, batch):
-    """GraphBuilder::set_fuse_dwpw through the predictor and the kernel class: a depthwise conv takes its 1x1 consumer
-    over (HipConvFusion::pw_*, lite/kernels/hip/conv_fusion.h).  Where the shape fits, ONE launch of plhip_dwpw_fused_int8 (the stride-1 pairs), else the two
-    kernels inside the one instruction (the stride-2 pairs; at these small batches also the tiles touching > 4 images).
-    Every variable the program still produces equals the oracle's: int8 bit for bit, fp32 within 1e-5."""
+@pytest.mark.parametrize("which,batch,mode", [("mobilenet_v1", 2, None), ("mobilenet_v1", 9, None), ("mobilenet_v1", 3, True), ("mobilenet_v2", 3, True)])
+def test_dwpw_fusion_equals_the_oracle_graph(lite, wl, plref, which, batch, mode):
+    """Depthwise -> pointwise fusion through the predictor and the kernel class (GraphBuilder fusion D; HipConvFusion::pw_*,
+    lite/kernels/hip/conv_fusion.h).  mode None = the DEFAULT lowering: the pairs the fused kernel takes (MobileNetV1's five
+    512 -> 512 pairs at 14 x 14) are ONE launch of plhip_dwpw_fused_int8 each; mode True = every eligible pair is one
+    instruction, the shapes outside the kernel as two launches inside it.  Every variable the program still produces equals
+    the oracle's: int8 bit for bit, fp32 within 1e-5."""
     net = wl.mobilenet_v1_net() if which == "mobilenet_v1" else wl.mobilenet_v2_net()
     img = np.random.default_rng(350 + batch).uniform(-1, 1, (batch, 3, 224, 224)).astype(np.float32)
     ref = graph_oracle.forward(plref, net, img)
-    p, out = _run_graph(lite, wl, net, img, fuse=True, fuse_dwpw=True)
+    p, out = _run_graph(lite, wl, net, img, fuse=True, fuse_dwpw=mode)
     try:
         plan = p.graph_plan()
         fused_lines = [l for l in plan if "+pw=" in l]
-        assert len(fused_lines) == (13 if which == "mobilenet_v1" else 2)
+        assert len(fused_lines) == ((13 if mode else 5) if which == "mobilenet_v1" else 2)
         names = p.kernel_names()
         n_one_launch = sum("conv_depthwise_3x3_pointwise_1x1_fused" in n for n in names)
         n_two = sum("conv_depthwise_int8_hip+conv1x1s1" in n for n in names)
-        # (the default library carries no fused kernel: make EXPERIMENTS=1 builds it; then the stride-1 pairs are one launch.
-        #  Either way the instruction count and every value must be the same)
         assert n_one_launch + n_two == len(fused_lines), names
+        assert n_one_launch == (5 if which == "mobilenet_v1" else 0), names
         gone = {l.split(" via=")[1].split(" ")[0] for l in fused_lines}
         n_i8 = 0
         for l in plan:

@@ -28,8 +28,26 @@ def _plan(lite, wl, net, batch=2, fuse=False, fuse_dwpw=False):
         p.close()
 
 
+def test_default_dwpw_fusion_takes_the_pairs_the_fused_kernel_takes(lite, wl):
+    """Default lowering (GraphBuilder fusion D, mode 2): the shapes are propagated from the feed and a depthwise conv takes
+    its 1x1 consumer over only where plhip_dwpw_fused_supported says the fused kernel runs the pair as ONE launch:
+    MobileNetV1's five 512 -> 512 pairs at 14 x 14, at any batch; MobileNetV2 has no such pair (its 14 x 14 project convs
+    have 64 / 96 output channels)."""
+    net = wl.mobilenet_v1_net()
+    for batch in (1, 128):
+        off, dflt = _plan(lite, wl, net, batch=batch, fuse=True, fuse_dwpw=False), _plan(lite, wl, net, batch=batch, fuse=True, fuse_dwpw=None)
+        fl = [l for l in dflt if "+pw=" in l]
+        assert len(dflt) == len(off) - 5 and len(fl) == 5
+        assert [l.split(" out=")[1].split(" ")[0] for l in fl] == ["pw8", "pw9", "pw10", "pw11", "pw12"]
+        assert [l.split(" via=")[1].split(" ")[0] for l in fl] == ["dw8", "dw9", "dw10", "dw11", "dw12"]
+    v2 = wl.mobilenet_v2_net(res=64)
+    assert not any("+pw=" in l for l in _plan(lite, wl, v2, fuse=True, fuse_dwpw=None))
+    # the reference program (no kHIP fusion) is untouched by the default
+    assert not any("+pw=" in l for l in _plan(lite, wl, net, fuse=False, fuse_dwpw=None))
+
+
 def test_opt_in_dwpw_fusion_plan(lite, wl):
-    """GraphBuilder::set_fuse_dwpw: every depthwise_conv2d[int8_out] of MobileNetV1 has exactly one consumer, a plain 1x1
+    """GraphBuilder::set_fuse_dwpw(true): every depthwise_conv2d[int8_out] of MobileNetV1 has exactly one consumer, a plain 1x1
     conv: 13 instructions disappear, the fused line carries the depthwise output scale (= the pointwise input scale) and the
     pointwise kernel choice; MobileNetV2's project convs that carry a fused residual tail keep their own instruction."""
     net = wl.mobilenet_v1_net()
@@ -42,8 +60,7 @@ def test_opt_in_dwpw_fusion_plan(lite, wl):
     assert " out=pw2 " in fl[0] and "via=dw2" in fl[0] and "oscale=%.9g" % float(W["pw2"]["in_scale"]) in fl[0]
     assert "pw_oscale=%.9g" % float(W["dw3"]["in_scale"]) in fl[0]
     assert not any(l.startswith("conv2d/") and " in=dw" in l for l in fused)
-    # default stays off
-    assert not any("+pw=" in l for l in base)
+    assert not any("+pw=" in l for l in base)  # base = fusion D switched off
     v2 = wl.mobilenet_v2_net(res=64)
     b2, f2 = _plan(lite, wl, v2, fuse=True), _plan(lite, wl, v2, fuse=True, fuse_dwpw=True)
     # a project conv that carries a fused tail (residual add and / or the calib copy for the next block) is not taken over

@@ -24,6 +24,8 @@ def load(d, counter):
 
 
 def family(name):
+    if "fused_dwpw" in name:
+        return "dwpw_fused"
     if "depthwise" in name:
         return "depthwise3x3"
     if "conv3x3s2" in name or "conv7x7s2_stem" in name:
@@ -69,6 +71,15 @@ def main():
                                                 stderr=subprocess.DEVNULL).decode().strip()
     except Exception:  # noqa: BLE001 - no git on the GPU box
         res["commit"] = "unknown"
+    try:  # the kernel sources this pass measured: bench.py refuses the file when they have changed since
+        import importlib.util
+        import os
+        spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+        b_ = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b_)
+        res["csrc_sha256"] = b_.csrc_sha256()
+    except Exception as e:  # noqa: BLE001
+        res["csrc_sha256"] = "unknown: %s" % e
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
