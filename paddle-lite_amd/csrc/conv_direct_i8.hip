@@ -68,11 +68,8 @@ __device__ __forceinline__ void ds2_store(const DirectS2Args& a, size_t off, int
     const float s2 = s + s, b2 = bi + bi;
     uint32_t pk;
     if (ACT == ACT_RELU || ACT == ACT_RELU6) {
-      uint32_t t[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t[j] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)acc[j], s2, b2), lo2, hi2);
-      const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-      pk = round_half_up4_u8(p);
+      pk = pack4_nn_rtz(__fmaf_rn((float)acc[0], s2, b2), __fmaf_rn((float)acc[1], s2, b2), __fmaf_rn((float)acc[2], s2, b2),
+                        __fmaf_rn((float)acc[3], s2, b2), hi2);
     } else {
       int q[4];
 #pragma unroll

@@ -15,13 +15,9 @@ __device__ __forceinline__ uint32_t fastdiv_u31(uint32_t n, uint32_t magic, int 
 template <int ACT>
 __device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, float b2, float alpha, float lo2, float hi2,
                                                 uint32_t ones = 0x01010101u) {
-  if (ACT == ACT_RELU || ACT == ACT_RELU6) {
-    uint32_t t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)a[j], s2, b2), lo2, hi2);
-    const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-    return __builtin_amdgcn_lerp(p, 0u, ones);  // round_half_up4_u8 (plhip_device.h)
-  }
+  if (ACT == ACT_RELU || ACT == ACT_RELU6)  // (lo2 == 0: the conversion saturates negative values to it)
+    return pack4_nn_rtz(__fmaf_rn((float)a[0], s2, b2), __fmaf_rn((float)a[1], s2, b2), __fmaf_rn((float)a[2], s2, b2),
+                        __fmaf_rn((float)a[3], s2, b2), hi2, ones);
   int q[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -33,28 +29,10 @@ __device__ __forceinline__ uint32_t dw_requant4(const int (&a)[4], float s2, flo
   return pack4_i8(q[0], q[1], q[2], q[3]);
 }
 
-// relu / relu6 requantisation of 4 accumulators on doubled values, the float -> byte step on v_cvt_pk_u8_f32 under
-// round-toward-zero: truncation, saturation to 0..255 and the byte insert in ONE instruction per value instead of
-// v_cvt_u32_f32 + shift / or (tools/probe_cvt_rtz.hip on the device: == trunc(sat(x, 0, 255)) on 2^20 values incl. every
-// tie and both neighbours of every integer; v_fma_f32 issued behind the restore rounds to nearest again, one issued INSIDE
-// the window does not: the mode switch and the four conversions are therefore ONE asm statement that nothing else can
-// enter).  hi2 <= 254 caps the doubled value first (255 would finish as 128); negative values saturate to 0 (relu).
-// Per value: v_cvt_f32_i32, v_fma_f32, v_min_f32, v_cvt_pk_u8_f32 + 1/4 v_lerp_u8 = 4.25 VALU (was 5: the conversion to
-// an integer, then or / shift to pack).  MODE.fp_round (bits 1:0) is 0 = nearest-even for HIP kernels and is restored to it.
+// relu / relu6 requantisation of 4 accumulators on doubled values (pack4_nn_rtz, plhip_device.h)
 __device__ __forceinline__ uint32_t requant4_nn_rtz(const int (&a)[4], float s2, float b2, float hi2, uint32_t ones = 0x01010101u) {
-  float y[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) y[j] = __builtin_fminf(__fmaf_rn((float)a[j], s2, b2), hi2);
-  uint32_t p;
-  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-      "v_cvt_pk_u8_f32 %0, %1, 0, 0\n\t"
-      "v_cvt_pk_u8_f32 %0, %2, 1, %0\n\t"
-      "v_cvt_pk_u8_f32 %0, %3, 2, %0\n\t"
-      "v_cvt_pk_u8_f32 %0, %4, 3, %0\n\t"
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-      : "=&v"(p)
-      : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
-  return __builtin_amdgcn_lerp(p, 0u, ones);
+  return pack4_nn_rtz(__fmaf_rn((float)a[0], s2, b2), __fmaf_rn((float)a[1], s2, b2), __fmaf_rn((float)a[2], s2, b2),
+                      __fmaf_rn((float)a[3], s2, b2), hi2, ones);
 }
 
 // Byte-validity masks of a row window of ND dwords whose byte 0 is input column `start` (may be negative: left padding):

@@ -65,8 +65,9 @@ __device__ __forceinline__ void fw_load_row(const int8_t* __restrict__ xs, uint3
 
 // MTW: 32-row m tiles per wave (M = 256 MTW).  OUT: output kind.  DWNN / PWNN: the depthwise / pointwise activation is
 // relu or relu6 (the packed non-negative requantisation); else none / leaky (leaky with slope 1 for none: exact).
-// EXP (timing experiments only, results are wrong): 1 = no MFMAs in the produce + consume rounds, 2 = no depthwise arithmetic there
-template <int MTW, int OUT, bool DWNN, bool PWNN, int EXP = 0, int SPLIT = 0, int NEWQ = 1>
+// EXP (timing experiments only, results are wrong): 1 = no MFMAs in the produce + consume rounds, 2 = no depthwise arithmetic there,
+// 3 = no input-row fetches there (the arithmetic runs on stale rows), 4 = no weight fetches there
+template <int MTW, int OUT, bool DWNN, bool PWNN, int EXP = 0, int ORDER_T = 1, int NEWQ = 1>
 __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   const GemmArgs& g = a.pw;
   PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.dw_w); PLHIP_PRELOAD(a.dw_scale); PLHIP_PRELOAD(a.dw_bias); PLHIP_PRELOAD(a.dw_act);
@@ -180,10 +181,11 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   // into the same registers behind their last use.  CONSUME: K-steps 4 rc .. 4 rc + 3 (W) multiplied, the next four fetched.
   // The MFMAs are dealt over the 9 row chunks of the task so that every chunk carries VALU and matrix work side by side.
   using std::integral_constant;
-  // ORDER (produce + consume rounds): 0 = the MFMAs dealt over the 9 row chunks; 1 = all MFMAs, then the task; 2 = the task,
-  // then all MFMAs.  The two waves of a SIMD (w and w + 4) run the same code in step behind each barrier: with order 0 both
-  // reach their MFMAs together and their VALU bursts together.  Orders 1 / 2 on the two halves of the block put one wave's
-  // matrix burst beside the other's depthwise arithmetic.
+  // ORDER: 1 (default) = TAPS FIRST: the 9 row chunks' window cuts and v_dot4 taps with no MFMA between them, then the 7
+  // requantisation slices with the round's MFMAs dealt over them.  v_dot4_i32_i8 runs on the matrix pipe: beside an MFMA it
+  // waits for it (tools/probe_coexec.hip: one wave's MFMA + 8 fma take 51 cycles, MFMA + 8 dot4 90; a dot4-only wave beside an
+  // MFMA-only wave runs at 9.5 cycles per dot4), while cvt / fma / min / perm overlap with it.  0 = everything dealt over the
+  // row chunks (the first form: rounds took MFMA time + VALU time, profiles/r04_fused_timeline_order0.txt).
   auto round = [&](auto produce_c, auto consume_c, auto order_c, int rp, int rc) __attribute__((always_inline)) {
     constexpr bool PRODUCE = decltype(produce_c)::value, CONSUME = decltype(consume_c)::value;
     constexpr int ORDER = decltype(order_c)::value;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
       acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, W[j][m], acc[n][m], 0, 0, 0);
       if constexpr (n == FW_NT - 1 && m == MTW - 1) {  // K-step j done: its registers take K-step j of the next round
         const int ksn = 4 * (rc + 1) + j;
-        fetch_w(j, ksn < KS ? ksn : KS - 1);
+        if constexpr (!(EXP == 4 && PRODUCE)) fetch_w(j, ksn < KS ? ksn : KS - 1);
       }
     };
     auto mfmas = [&](auto self, auto i_c, auto end_c) __attribute__((always_inline)) -> void {
@@ -236,63 +238,95 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
       constexpr int cum[10] = {0, 1, 3, 7, 11, 15, 19, 23, 28, 32};
       return cum[t] * NM / 32;
     };
-    auto chunk = [&](auto t_c) __attribute__((always_inline)) {
+    auto taps = [&](auto t_c) __attribute__((always_inline)) {
       constexpr int t = decltype(t_c)::value;
-      if constexpr (CONSUME && !(EXP == 1 && PRODUCE) && ORDER == 0) mfmas(mfmas, integral_constant<int, mstart(t)>{}, integral_constant<int, mstart(t + 1)>{});
-      if constexpr (PRODUCE && !(EXP == 2 && CONSUME)) {
-        const uint32_t e0 = __builtin_amdgcn_perm(in[t][1], in[t][0], sel_lo), e1 = __builtin_amdgcn_perm(in[t][1], in[t][0], sel_hi);
-        uint32_t win[4];
-        win[0] = e0;
-        win[1] = __builtin_amdgcn_alignbyte(e1, e0, 1);
-        win[2] = __builtin_amdgcn_alignbyte(e1, e0, 2);
-        win[3] = __builtin_amdgcn_alignbyte(e1, e0, 3);
+      const uint32_t e0 = __builtin_amdgcn_perm(in[t][1], in[t][0], sel_lo), e1 = __builtin_amdgcn_perm(in[t][1], in[t][0], sel_hi);
+      uint32_t win[4];
+      win[0] = e0;
+      win[1] = __builtin_amdgcn_alignbyte(e1, e0, 1);
+      win[2] = __builtin_amdgcn_alignbyte(e1, e0, 2);
+      win[3] = __builtin_amdgcn_alignbyte(e1, e0, 3);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int o = t - r;
-          if (o < 0 || o >= FW_TR) continue;
+      for (int r = 0; r < 3; ++r) {
+        const int o = t - r;
+        if (o < 0 || o >= FW_TR) continue;
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            dacc[o][jj] = r == 0 ? sdot4_first(win[jj], t == 0 ? wr0t : wr[0])
-                                 : __builtin_amdgcn_sdot4((int)win[jj], (int)(t == 8 ? wr2b : wr[r]), dacc[o][jj], false);
-        }
-        // the next task's row t into the registers just consumed
-        load_row(integral_constant<int, t>{}, noff, in[t]);
-        if constexpr (t == 2) {
-          const int8_t* wp = a.dw_w + (size_t)nch * 9;
-          uint32_t w0, w1, w2;
-          __builtin_memcpy(&w0, wp, 4);
-          __builtin_memcpy(&w1, wp + 3, 4);
-          __builtin_memcpy(&w2, wp + 5, 4);
-          nwr[0] = w0 & 0xffffffu;
-          nwr[1] = w1 & 0xffffffu;
-          nwr[2] = w2 >> 8;
-          ndsc = a.dw_scale[nch];
-          ndbi = (a.dw_bias ? a.dw_bias : a.dw_scale)[nch];  // no branch inside the round
-          if (!a.dw_bias) ndbi = 0.f;
-        }
-        if constexpr (t >= 2) {  // output row t - 2 is complete
-          constexpr int o = t - 2;
-          const uint32_t pk = DWNN ? (NEWQ ? requant4_nn_rtz(dacc[o], dsc, dbi, dw_hi2, a.ones) : dw_requant4<ACT_RELU6>(dacc[o], dsc, dbi, 0.f, 0.f, dw_hi2, a.ones))
-                                   : dw_requant4<ACT_LEAKY>(dacc[o], dsc, dbi, dw_leak, -254.f, 254.f);
-          *reinterpret_cast<uint32_t*>(fw_lds + (wb ^ (uint32_t)(o << 4))) = pk;
-        }
+        for (int jj = 0; jj < 4; ++jj)
+          dacc[o][jj] = r == 0 ? sdot4_first(win[jj], t == 0 ? wr0t : wr[0])
+                               : __builtin_amdgcn_sdot4((int)win[jj], (int)(t == 8 ? wr2b : wr[r]), dacc[o][jj], false);
+      }
+      // the next task's row t into the registers just consumed
+      if constexpr (!(EXP == 3 && CONSUME)) load_row(integral_constant<int, t>{}, noff, in[t]);
+      if constexpr (t == 2) {
+        const int8_t* wp = a.dw_w + (size_t)nch * 9;
+        uint32_t w0, w1, w2;
+        __builtin_memcpy(&w0, wp, 4);
+        __builtin_memcpy(&w1, wp + 3, 4);
+        __builtin_memcpy(&w2, wp + 5, 4);
+        nwr[0] = w0 & 0xffffffu;
+        nwr[1] = w1 & 0xffffffu;
+        nwr[2] = w2 >> 8;
+        ndsc = a.dw_scale[nch];
+        ndbi = (a.dw_bias ? a.dw_bias : a.dw_scale)[nch];  // no branch inside the round
+        if (!a.dw_bias) ndbi = 0.f;
+      }
+    };
+    auto finish = [&](auto o_c) __attribute__((always_inline)) {  // output row o is complete: requantise, into the image
+      constexpr int o = decltype(o_c)::value;
+      const uint32_t pk = DWNN ? (NEWQ ? requant4_nn_rtz(dacc[o], dsc, dbi, dw_hi2, a.ones) : dw_requant4<ACT_RELU6>(dacc[o], dsc, dbi, 0.f, 0.f, dw_hi2, a.ones))
+                               : dw_requant4<ACT_LEAKY>(dacc[o], dsc, dbi, dw_leak, -254.f, 254.f);
+      *reinterpret_cast<uint32_t*>(fw_lds + (wb ^ (uint32_t)(o << 4))) = pk;
+    };
+    constexpr bool DO_P = PRODUCE && !(EXP == 2 && CONSUME), DO_C = CONSUME && !(EXP == 1 && PRODUCE);
+    auto chunk = [&](auto t_c) __attribute__((always_inline)) {  // ORDER 0: row chunk t with its share of the MFMAs
+      constexpr int t = decltype(t_c)::value;
+      if constexpr (DO_C) mfmas(mfmas, integral_constant<int, mstart(t)>{}, integral_constant<int, mstart(t + 1)>{});
+      if constexpr (DO_P) {
+        taps(t_c);
+        if constexpr (t >= 2) finish(integral_constant<int, t - 2>{});
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    if constexpr (CONSUME && ORDER == 1 && !(EXP == 1 && PRODUCE)) {
-      mfmas(mfmas, integral_constant<int, 0>{}, integral_constant<int, NM>{});
+    // first MFMA of requantisation slice o (o = 7: end), ORDER 1
+    constexpr auto m1start = [](int o) {
+      constexpr int cum[8] = {0, 5, 10, 14, 19, 23, 28, 32};
+      return cum[o] * NM / 32;
+    };
+    auto slice = [&](auto o_c) __attribute__((always_inline)) {  // ORDER 1: requantisation slice o with its share of the MFMAs
+      constexpr int o = decltype(o_c)::value;
+      if constexpr (DO_C) mfmas(mfmas, integral_constant<int, m1start(o)>{}, integral_constant<int, m1start(o + 1)>{});
+      if constexpr (DO_P) finish(o_c);
       __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (ORDER == 0 || !DO_P) {
+      chunk(integral_constant<int, 0>{});
+      chunk(integral_constant<int, 1>{});
+      chunk(integral_constant<int, 2>{});
+      chunk(integral_constant<int, 3>{});
+      chunk(integral_constant<int, 4>{});
+      chunk(integral_constant<int, 5>{});
+      chunk(integral_constant<int, 6>{});
+      chunk(integral_constant<int, 7>{});
+      chunk(integral_constant<int, 8>{});
+    } else {
+      taps(integral_constant<int, 0>{});
+      taps(integral_constant<int, 1>{});
+      taps(integral_constant<int, 2>{});
+      taps(integral_constant<int, 3>{});
+      taps(integral_constant<int, 4>{});
+      taps(integral_constant<int, 5>{});
+      taps(integral_constant<int, 6>{});
+      taps(integral_constant<int, 7>{});
+      taps(integral_constant<int, 8>{});
+      __builtin_amdgcn_sched_barrier(0);
+      slice(integral_constant<int, 0>{});
+      slice(integral_constant<int, 1>{});
+      slice(integral_constant<int, 2>{});
+      slice(integral_constant<int, 3>{});
+      slice(integral_constant<int, 4>{});
+      slice(integral_constant<int, 5>{});
+      slice(integral_constant<int, 6>{});
     }
-    chunk(integral_constant<int, 0>{});
-    chunk(integral_constant<int, 1>{});
-    chunk(integral_constant<int, 2>{});
-    chunk(integral_constant<int, 3>{});
-    chunk(integral_constant<int, 4>{});
-    chunk(integral_constant<int, 5>{});
-    chunk(integral_constant<int, 6>{});
-    chunk(integral_constant<int, 7>{});
-    chunk(integral_constant<int, 8>{});
-    if constexpr (CONSUME && ORDER == 2 && !(EXP == 1 && PRODUCE)) mfmas(mfmas, integral_constant<int, 0>{}, integral_constant<int, NM>{});
     if constexpr (PRODUCE && !(EXP == 2 && CONSUME)) {
       wr[0] = nwr[0];
       wr[1] = nwr[1];
@@ -308,15 +342,13 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
   fetch_w(2, 2 < KS ? 2 : KS - 1);
   fetch_w(3, 3 < KS ? 3 : KS - 1);
   PLHIP_FW_STAMP(2);
-  using O0 = integral_constant<int, 0>;
-  round(std::true_type{}, std::false_type{}, O0{}, 0, 0);
+  using OD = integral_constant<int, ORDER_T>;
+  round(std::true_type{}, std::false_type{}, OD{}, 0, 0);
   xoff += (R > 1 ? 1 : 0) * 128 * 196;
   PLHIP_FW_STAMP(3);
   __syncthreads();
   for (int r = 1; r < R; ++r) {
-    if (SPLIT == 0) round(std::true_type{}, std::true_type{}, O0{}, r, r - 1);
-    else if (wave < 4) round(std::true_type{}, std::true_type{}, integral_constant<int, 1>{}, r, r - 1);
-    else round(std::true_type{}, std::true_type{}, integral_constant<int, 2>{}, r, r - 1);
+    round(std::true_type{}, std::true_type{}, OD{}, r, r - 1);
     xoff += (r + 1 < R ? 1 : 0) * 128 * 196;
     if (r < 5) PLHIP_FW_STAMP(4 + 2 * (r - 1));
     __syncthreads();
@@ -332,22 +364,41 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
       if (g.bias) pbi[m] = g.bias[(mt0 + m) * 32 + c];
     }
   }
-  round(std::false_type{}, std::true_type{}, O0{}, R, R - 1);
-  PLHIP_FW_STAMP(12);
-
-  // ------------------------------------------------------------------ epilogue
+  // ------------------------------------------------------------------ last K-steps + epilogue
   // accumulator register r of n tile n: pixel 32 n + 8 (r >> 2) + 4 h + (r & 3) = output row 2 n + (r >> 3), column
   // 8 ((r >> 2) & 1) + 4 h + (r & 3) of the 16-wide chunk; lane (c, h) owns output channel 32 (mt0 + m) + c.
   const int orow0 = FW_TR * hf;
   if (OUT == OUT_I8) {
+    // int8: the last round's 4 K-steps n-tile-major, so that tile n - 1 is requantised (fma / min / cvt: they overlap with the
+    // matrix pipe) in the shadow of tile n's MFMAs; only the last tile's epilogue is exposed
     const float hi2 = g.act == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
     const float leak = g.act == ACT_LEAKY ? g.alpha : 1.f;
     uint8_t* stg = fw_lds + (size_t)KS * FW_KSTEP + wave * (32 * MTW * FW_SP);
+    const uint32_t rbf = (uint32_t)(R - 1) * (4 * FW_KSTEP);
+    v2i flo[2][4], fhi[2][4];  // fragments of the 4 K-steps of one n tile, two sets
+    auto read_tile = [&](auto n_c) __attribute__((always_inline)) {
+      constexpr int n = decltype(n_c)::value;
+      const uint32_t ta = (tr00 + rbf) ^ (uint32_t)(n << 5);
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-      const float s2 = psc[m] + psc[m], b2 = pbi[m] + pbi[m];
+      for (int j = 0; j < 4; ++j) {
+        flo[n & 1][j] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i_ptr_t)(fw_lds + ta + j * FW_KSTEP));
+        fhi[n & 1][j] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i_ptr_t)(fw_lds + ta + j * FW_KSTEP + 1024));
+      }
+    };
+    auto mfma_tile = [&](auto n_c) __attribute__((always_inline)) {
+      constexpr int n = decltype(n_c)::value;
 #pragma unroll
-      for (int n = 0; n < FW_NT; ++n) {
+      for (int j = 0; j < 4; ++j) {
+        const v4i av = {flo[n & 1][j][0], flo[n & 1][j][1], fhi[n & 1][j][0], fhi[n & 1][j][1]};
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, W[j][m], acc[n][m], 0, 0, 0);
+      }
+    };
+    auto epi_tile = [&](auto n_c) __attribute__((always_inline)) {
+      constexpr int n = decltype(n_c)::value;
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const float s2 = psc[m] + psc[m], b2 = pbi[m] + pbi[m];
         uint32_t edw[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -369,7 +420,28 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
           p[6] = (uint16_t)d3;
         }
       }
-    }
+    };
+    using I0 = integral_constant<int, 0>;
+    using I1 = integral_constant<int, 1>;
+    using I2 = integral_constant<int, 2>;
+    using I3 = integral_constant<int, 3>;
+    read_tile(I0{});
+    read_tile(I1{});
+    mfma_tile(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_tile(I2{});
+    mfma_tile(I1{});
+    epi_tile(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_tile(I3{});
+    mfma_tile(I2{});
+    epi_tile(I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tile(I3{});
+    epi_tile(I2{});
+    __builtin_amdgcn_sched_barrier(0);
+    PLHIP_FW_STAMP(12);
+    epi_tile(I3{});
     PLHIP_FW_STAMP(13);
     // copy-out: lane -> (row lane >> 3 of a group of 8, 16-byte piece lane & 7); a channel row is 98 contiguous bytes
     const int piece = lane & 7, rsub = lane >> 3;
@@ -386,6 +458,8 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
       }
     }
   } else {
+    round(std::false_type{}, std::true_type{}, OD{}, R, R - 1);
+    PLHIP_FW_STAMP(12);
     const float fcap = g.act == ACT_RELU6 ? g.alpha : __builtin_huge_valf();
     const float flo = (g.act == ACT_RELU || g.act == ACT_RELU6) ? 0.f : -__builtin_huge_valf();
 #pragma unroll
@@ -465,15 +539,27 @@ static void launch_fused_t(const FusedArgs& a, hipStream_t s) {
   } while (0)
   if (OUT == OUT_I8 && MTW == 2 && dwnn && pwnn && (a.pw.dbg & 12)) {
     if ((a.pw.dbg & 12) == 4) {
-      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 1, 1>;
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 0, 1>;
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
     } else if ((a.pw.dbg & 12) == 8) {
-      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 0, 0>;
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 1, 0>;
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
     } else {
-      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 1, 0>;
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 0, 0, 0>;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    }
+    return;
+  }
+  if (OUT == OUT_I8 && MTW == 2 && dwnn && pwnn && (a.pw.dbg & 3) == 3) {
+    if (a.pw.dbg & 16) {
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 4>;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
+    } else {
+      auto kfn = fused_dwpw14_kernel<MTW, OUT, true, true, 3>;
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, s, a);
     }

@@ -149,10 +149,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
             const bool nonneg = g.res ? g.res_relu != 0 : (ACT == ACT_RELU || ACT == ACT_RELU6);
             if (nonneg) {
               const float i2 = g.inv_scale2 + g.inv_scale2;
-              uint32_t t[4];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) t[i] = (uint32_t)__builtin_amdgcn_fmed3f(i2 * f[i], 0.f, 254.f);
-              packed = round_half_up4_u8((t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16));
+              packed = pack4_nn_rtz(i2 * f[0], i2 * f[1], i2 * f[2], i2 * f[3], 254.f);
             } else {
               packed = pack4_i8(round_sat_i8(g.inv_scale2 * f[0]), round_sat_i8(g.inv_scale2 * f[1]),
                                 round_sat_i8(g.inv_scale2 * f[2]), round_sat_i8(g.inv_scale2 * f[3]));
@@ -174,12 +171,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const v16i (&ac
           const int vv[4] = {v0, v1, v2, v3};
           uint32_t packed;
           if (ACT == ACT_RELU || ACT == ACT_RELU6) {
-            uint32_t t[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              t[i] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)vv[i], s2, b2), lo2, hi2);  // trunc, 0..254
-            const uint32_t p = (t[0] | (t[1] << 8)) | ((t[2] | (t[3] << 8)) << 16);
-            packed = round_half_up4_u8(p);
+            packed = pack4_nn_rtz(__fmaf_rn((float)vv[0], s2, b2), __fmaf_rn((float)vv[1], s2, b2), __fmaf_rn((float)vv[2], s2, b2),
+                                  __fmaf_rn((float)vv[3], s2, b2), hi2);
           } else {
             int q[4];
 #pragma unroll

@@ -60,11 +60,8 @@ __device__ __forceinline__ v4i tr_requant_chunk(const v16i& acc, float s2, float
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     if (ACT == ACT_RELU || ACT == ACT_RELU6) {
-      uint32_t tt[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) tt[e] = (uint32_t)__builtin_amdgcn_fmed3f(__fmaf_rn((float)acc[4 * gq + e], s2, b2), lo2, hi2);
-      const uint32_t p = (tt[0] | (tt[1] << 8)) | ((tt[2] | (tt[3] << 8)) << 16);
-      dw[gq] = round_half_up4_u8(p);
+      dw[gq] = pack4_nn_rtz(__fmaf_rn((float)acc[4 * gq], s2, b2), __fmaf_rn((float)acc[4 * gq + 1], s2, b2),
+                            __fmaf_rn((float)acc[4 * gq + 2], s2, b2), __fmaf_rn((float)acc[4 * gq + 3], s2, b2), hi2);
     } else {
       int qv[4];
 #pragma unroll

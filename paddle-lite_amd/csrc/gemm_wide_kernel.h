@@ -284,11 +284,8 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_wide_kernel(GemmArgs g) {
     if constexpr (OUT == OUT_I8) {
       float y2 = __fmaf_rn((float)acc[t][r], s2, b2);
       if constexpr (NONNEG) {
-        ebytes[r & 3] = (uint32_t)__builtin_amdgcn_fmed3f(y2, lo2, hi2);  // trunc, 0..254
-        if constexpr ((r & 3) == 3) {
-          const uint32_t p = (ebytes[0] | (ebytes[1] << 8)) | ((ebytes[2] | (ebytes[3] << 8)) << 16);
-          edw[r >> 2] = round_half_up4_u8(p);
-        }
+        ef[r & 3] = y2;  // the 4th slice of a register group converts and packs all four (pack4_nn_rtz: 4.25 VALU per output)
+        if constexpr ((r & 3) == 3) edw[r >> 2] = pack4_nn_rtz(ef[0], ef[1], ef[2], ef[3], hi2);
       } else {
         y2 = y2 > 0.f ? y2 : leak * y2;
         const int tq = (int)__builtin_amdgcn_fmed3f(y2, lo2, hi2);

@@ -909,7 +909,7 @@ extern "C" int plhip_debug_set(const char* key, int value) {
   if (!key) return -1;
   static int fused_bits = 0;
   if (!strcmp(key, "fused_stamps")) { fused_bits = (fused_bits & ~32) | (value ? 32 : 0); plhip::debug_set_fused(fused_bits); return 0; }
-  if (!strcmp(key, "fused_exp")) { fused_bits = (fused_bits & ~15) | (value & 15); plhip::debug_set_fused(fused_bits); return 0; }  // timing experiments, wrong results
+  if (!strcmp(key, "fused_exp")) { fused_bits = (fused_bits & ~31) | (value & 31); plhip::debug_set_fused(fused_bits); return 0; }  // timing experiments, wrong results
   return -1;
 }
 extern "C" int plhip_debug_read_stamps(void* dst_host, size_t bytes) {

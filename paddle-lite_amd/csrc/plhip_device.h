@@ -50,6 +50,31 @@ __device__ __forceinline__ uint32_t round_half_up4_u8(uint32_t packed_doubled) {
   return __builtin_amdgcn_lerp(packed_doubled, 0u, 0x01010101u);
 }
 
+// relu / relu6 requantisation, last step: four DOUBLED values (each <= hi2 <= 254 after the v_min_f32 here; negative ones are
+// the relu's zeros) -> four int8 in one dword.  The float -> byte conversion is v_cvt_pk_u8_f32 under round-toward-zero:
+// truncation, saturation to 0..255 and the byte insert in ONE instruction per value instead of v_cvt_u32_f32 + shift / or
+// (tools/probe_cvt_rtz.hip on the device: == trunc(sat(x, 0, 255)) on 2^20 values incl. every tie and both neighbours of every
+// integer; a v_fma_f32 issued behind the restore rounds to nearest again, one issued INSIDE the window does not: the mode
+// switch and the four conversions are therefore ONE asm statement that nothing else can enter).  Per value: v_cvt_f32_i32,
+// v_fma_f32, v_min_f32, v_cvt_pk_u8_f32 + 1/4 v_lerp_u8 = 4.25 VALU (was 5).  MODE.fp_round (bits 1:0) is 0 = nearest-even
+// in every kernel of this library and is restored to it.  Bit-identical to trunc(med3(y, 0, hi2)) -> (t + 1) >> 1.
+__device__ __forceinline__ uint32_t pack4_nn_rtz(float y0, float y1, float y2, float y3, float hi2, uint32_t ones = 0x01010101u) {
+  y0 = __builtin_fminf(y0, hi2);
+  y1 = __builtin_fminf(y1, hi2);
+  y2 = __builtin_fminf(y2, hi2);
+  y3 = __builtin_fminf(y3, hi2);
+  uint32_t p;
+  asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_cvt_pk_u8_f32 %0, %1, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %0, %2, 1, %0\n\t"
+      "v_cvt_pk_u8_f32 %0, %3, 2, %0\n\t"
+      "v_cvt_pk_u8_f32 %0, %4, 3, %0\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(p)
+      : "v"(y0), "v"(y1), "v"(y2), "v"(y3));
+  return __builtin_amdgcn_lerp(p, 0u, ones);  // (t + 1) >> 1 per byte
+}
+
 __device__ __forceinline__ uint32_t pack4_i8(int q0, int q1, int q2, int q3) {
   // low byte of each int32 -> one dword, little endian
   uint32_t lo = __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);  // [q0.b0, q1.b0, 0, 0]
