@@ -758,7 +758,7 @@ def main():
                         "ms_per_step_min_median_max": [round(1e3 * min(wins) / args.steps, 4), round(1e3 * elapsed / args.steps, 4),
                                                        round(1e3 * max(wins) / args.steps, 4)]},
             "selfcheck": selfcheck, "strong": strong,
-            "single_stream": serial, "roofline": roof, "roofline_by_family": by_family(fam_out), "kernels": fam_out, "cpu_baseline": cpu,
+            "debug_knobs": dict(getattr(sys.modules.get("paddle_lite_amd.capi"), "KNOBS_SET", {})), "single_stream": serial, "roofline": roof, "roofline_by_family": by_family(fam_out), "kernels": fam_out, "cpu_baseline": cpu,
         }
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()

@@ -207,7 +207,8 @@ plhip_status plhip_elementwise_add_f32(plhip_ctx* ctx, const float* x, const flo
 plhip_status plhip_selftest(plhip_ctx* ctx);
 
 /* ---- diagnostics (no effect on results): switches of the shipped library are set HERE, never through the environment,
- * so that a stray variable cannot change which kernel a benchmark measures.  key: "fused_stamps" (1 = the fused
+ * so that a stray variable cannot change which kernel a benchmark measures.  Keys: the A/B knobs of DESIGN.md 3.6 without
+ * their former PLHIP_ prefix ("GEMM_WIDE", "CONV_PATCH", "DW_STAGE", "GEMM_DEBUG", ...), "fused_exp", and "fused_stamps" (1 = the fused
  * depthwise -> pointwise kernel records its in-kernel timeline, read back with plhip_debug_read_fw_stamps:
  * [tile][wave][16] shader-clock stamps).  Returns 0, or -1 for an unknown key. ---- */
 int plhip_debug_set(const char* key, int value);

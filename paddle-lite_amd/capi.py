@@ -68,6 +68,13 @@ class PlhipError(RuntimeError):
 
 
 _lib = None
+# Diagnostic knobs this PROCESS set through plhip_debug_set (the library itself never reads the environment).  The binding
+# forwards PLHIP_<KNOB>=<int> variables of the A/B scripts (tools/*.sh) explicitly and records them here;
+# bench.py prints the dict in its JSON line, so a measurement taken with a knob says so.
+KNOBS = ("STEM_MFMA", "CONV_PATCH", "CONV_PATCH_S2", "PATCH_DEBUG", "PATCH_DELAY", "STEM7", "DW_STAGE", "DW_STAGE_NP2", "DW_FASTV",
+         "DW5_DIRECT", "DW_RS1", "DW_RS2", "GEMM_VARIANT", "GEMM_AREG", "GEMM_MA", "GEMM_DEBUG", "SUBSAMPLE_1X1", "GEMM_TR", "TR_DELAY",
+         "TR_CFG", "GEMM_WIDE", "WIDE_NTT", "FC_MFMA", "IMPLICIT_GEMM")
+KNOBS_SET = {}
 
 
 def load():
@@ -80,6 +87,17 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.plhip_device_count.restype = i32
+    L.plhip_debug_set.argtypes = [C.c_char_p, i32]
+    L.plhip_debug_set.restype = i32
+    for k in KNOBS:
+        v = os.environ.get("PLHIP_" + k)
+        if v is not None:
+            if L.plhip_debug_set(k.encode(), int(v)) != 0:
+                raise PlhipError("unknown diagnostic knob %s" % k)
+            KNOBS_SET[k] = int(v)
+    if KNOBS_SET:
+        import sys
+        sys.stderr.write("capi: diagnostic knobs set from the environment: %s\n" % KNOBS_SET)
     L.plhip_ctx_create.argtypes = [i32, C.POINTER(vp)]
     L.plhip_ctx_create_on_stream.argtypes = [i32, vp, C.POINTER(vp)]
     L.plhip_ctx_destroy.argtypes = [vp]

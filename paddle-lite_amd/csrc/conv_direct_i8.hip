@@ -381,11 +381,7 @@ void launch_pack_conv3x3s2_direct(const int8_t* w_oihw, uint32_t* wp, int cin, i
 }
 
 void launch_conv3x3s2_direct(const DirectS2Args& a, int out, hipStream_t s) {
-  static int mfma_env = -1;
-  if (mfma_env < 0) {
-    const char* e = getenv("PLHIP_STEM_MFMA");
-    mfma_env = e ? atoi(e) : 1;
-  }
+  const int mfma_env = knob("STEM_MFMA", 1);
   const size_t esz = out == OUT_I8 ? 1 : 4;
   const long tensor = (long)a.n * a.cin * a.h * a.w;
   const int owq = a.ow >> 2;

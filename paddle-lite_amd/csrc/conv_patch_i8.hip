@@ -48,11 +48,7 @@ int debug_read_patch_stamps(void* dst, size_t bytes) {
 }
 
 static int patch_env() {  // PLHIP_CONV_PATCH=0: the ring-kernel implicit GEMM instead (A/B runs)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PLHIP_CONV_PATCH");
-    v = e ? atoi(e) : 1;
-  }
+  const int v = knob("CONV_PATCH", 1);
   return v;
 }
 
@@ -185,11 +181,7 @@ void launch_pad_rows8(PadArgs a, hipStream_t s) {  // a.pw % 8 == 0, a.total % 1
 int conv_patch_s2_row_pitch(int w, int pl, int pr) { return (((w + pl + pr + 1) >> 1) + 7) & ~7; }
 bool conv_patch_s2_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int w, int pl, int pr) {
   if (!patch_env()) return false;
-  static int s2_env = -1;
-  if (s2_env < 0) {
-    const char* e = getenv("PLHIP_CONV_PATCH_S2");  // 0 = the ring kernel's stride-2 implicit GEMM (A/B runs)
-    s2_env = e ? atoi(e) : 1;
-  }
+  const int s2_env = knob("CONV_PATCH_S2", 1);  // 0 = the ring kernel's stride-2 implicit GEMM (A/B runs)
   if (!s2_env) return false;
   if (kh != 3 || kw != 3 || sh != 2 || sw != 2 || dh != 1 || dw != 1 || groups != 1) return false;
   if (cin % 32 != 0 || cout <= 64) return false;  // whole 32-channel groups; the 4 x 1 wave layout
@@ -331,13 +323,9 @@ static inline void magic_u31(long d, unsigned& m, int& sh, bool general_pow2 = f
 }
 
 void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
-  static int dbg_env = -1;
-  if (dbg_env < 0) {
-    // its OWN variable (diagnostics only): 1 = no epilogue (timing experiments), 32 = timeline stamps.  (PLHIP_GEMM_DEBUG
+      // its OWN variable (diagnostics only): 1 = no epilogue (timing experiments), 32 = timeline stamps.  (PLHIP_GEMM_DEBUG
     // also re-routes the GEMM kernels of the other layers, e.g. 7-wide implicit-GEMM rows onto a kernel that cannot run them.)
-    const char* e = getenv("PLHIP_PATCH_DEBUG");
-    dbg_env = e ? atoi(e) : 0;
-  }
+  const int dbg_env = knob("PATCH_DEBUG", 0);
   a.dbg = dbg_env;
   a.stamps = (a.dbg & 32) ? patch_stamps_ptr() : nullptr;
   a.NCH = a.C / 32;
@@ -378,11 +366,7 @@ void launch_conv_patch(PatchArgs a, int out, hipStream_t s) {
   a.rounds = (a.T8 + NH * nq - 1) / (NH * nq);
   nq = (a.T8 + NH * a.rounds - 1) / (NH * a.rounds);  // the fewest blocks that need no more rounds
   a.NQ = nq;
-  static int delay_env = -1;
-  if (delay_env < 0) {
-    const char* e = getenv("PLHIP_PATCH_DELAY");  // s_sleep units (64 clocks) the second block of a CU starts late
-    delay_env = e ? atoi(e) : 0;
-  }
+  const int delay_env = knob("PATCH_DELAY", 0);  // s_sleep units (64 clocks) the second block of a CU starts late
   a.delay = delay_env;
   magic_u31(a.PWp, a.pw_m, a.pw_s, true);
   magic_u31(a.TPI, a.tpi_m, a.tpi_s);

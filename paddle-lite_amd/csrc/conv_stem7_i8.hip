@@ -26,11 +26,7 @@ namespace plhip {
 
 bool conv7x7s2_stem_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int n, int h, int w,
                               int oh, int ow, int pl) {
-  static int env = -1;
-  if (env < 0) {
-    const char* e = getenv("PLHIP_STEM7");  // 0 = the ring kernel's implicit GEMM (A/B runs)
-    env = e ? atoi(e) : 1;
-  }
+  const int env = knob("STEM7", 1);  // 0 = the ring kernel's implicit GEMM (A/B runs)
   if (!env) return false;
   if (!(groups == 1 && kh == 7 && kw == 7 && sh == 2 && sw == 2 && dh == 1 && dw == 1)) return false;
   if (cin * 7 > 4 * STEM7_KS || pl > 3 || (ow & 3) != 0 || w < 16 || cout < 1) return false;

@@ -616,19 +616,11 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
   magic(spp, a.div_spp_m, a.div_spp_s);
   magic(a.C, a.div_c_m, a.div_c_s);
   // output staging through LDS: int8 output, narrow planes, a wave = whole strips, strips = whole rows of the plane
-  static int stage_env = -1;
-  if (stage_env < 0) {
-    const char* e = getenv("PLHIP_DW_STAGE");
-    stage_env = e ? atoi(e) : 1;
-  }
+  const int stage_env = knob("DW_STAGE", 1);
   // (owq a power of two: a wave = 64 lanes = whole strips; otherwise a wave uses (64 / owq) * owq lanes: 63 of 64 on
   // 28-wide planes, 56 of 64 on 56-wide ones — the 14x14 layers went 19.3 -> 11.0 us with staging, and a 28x28 layer
   // moves the same bytes with the same arithmetic)
-  static int stage_np2 = -1;
-  if (stage_np2 < 0) {
-    const char* e = getenv("PLHIP_DW_STAGE_NP2");
-    stage_np2 = e ? atoi(e) : 1;
-  }
+  const int stage_np2 = knob("DW_STAGE_NP2", 1);
   // measured: 28-wide planes gain ~5 % (dw6 19.7 -> 18.7 us), 56-wide ones lose ~5 %: the store-request granularity that
   // staging cures is a narrow-row effect; stage_np2 = 2 forces it for every width <= 64
   const bool stage = stage_env && OUT == OUT_I8 && a.ow <= 64 && owq <= 64 && a.oh % rs == 0 &&
@@ -639,11 +631,7 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
   a.stage_bytes = stage ? (int)(((64 / owq) * rs * a.ow + 15) & ~15) : 0;
   const size_t lds = stage ? (size_t)4 * a.stage_bytes : 0;
   // fast row fetch: only the first / last row of a strip can leave the image, windows start inside the row
-  static int fast_env = -1;
-  if (fast_env < 0) {
-    const char* e = getenv("PLHIP_DW_FASTV");
-    fast_env = e ? atoi(e) : 1;
-  }
+  const int fast_env = knob("DW_FASTV", 1);
   constexpr int PV = (KS - 1) / 2;
   const bool fastv = fast_env && a.pt <= PV && (a.oh - 1) * S + KS - 1 - a.pt <= a.h - 1 + PV && a.oh % rs == 0 &&
                      (owq - 1) * 4 * S - a.pl < a.w;
@@ -667,30 +655,18 @@ static void launch_dw_direct_s(const DwArgs& a_in, int rs, hipStream_t s) {
 }
 
 static bool launch_dw_direct(const DwArgs& a, int out, hipStream_t s) {
-  static int k5_env = -1;
-  if (k5_env < 0) {
-    const char* e = getenv("PLHIP_DW5_DIRECT");  // 0 = 5x5 filters on the LDS-band kernel (A/B runs)
-    k5_env = e ? atoi(e) : 1;
-  }
+  const int k5_env = knob("DW5_DIRECT", 1);  // 0 = 5x5 filters on the LDS-band kernel (A/B runs)
   const bool k3 = a.kh == 3 && a.kw == 3, k5 = a.kh == 5 && a.kw == 5 && k5_env;
   if (!((k3 || k5) && a.dh == 1 && a.dw == 1 && a.sh == a.sw && (a.sw == 1 || a.sw == 2) && a.pl <= 3)) return false;
   if ((long)a.planes * a.h * a.w >= (1L << 31) || (long)a.planes * a.oh * a.ow >= (1L << 31)) return false;
   // rows per strip: amortise the 2-row halo while keeping many lanes (and bytes) in flight
   int rs;
-  static int rs1_env = -1;
-  if (rs1_env < 0) {
-    const char* e = getenv("PLHIP_DW_RS1");
-    rs1_env = e ? atoi(e) : 0;
-  }
+  const int rs1_env = knob("DW_RS1", 0);
   if (a.sw == 1 && (rs1_env == 4 || rs1_env == 7 || rs1_env == 8)) rs = rs1_env;
   else if (a.sw == 1) rs = (a.oh % 8 == 0) ? 8 : (a.oh % 7 == 0 ? 7 : (a.oh >= 8 ? 8 : (a.oh >= 5 ? 7 : 4)));
   else {
     // stride 2 fetches 2 rows per output row: a taller strip amortises the per-row fetch / mask work (VALU-bound op)
-    static int rs2_env = -1;
-    if (rs2_env < 0) {
-      const char* e = getenv("PLHIP_DW_RS2");
-      rs2_env = e ? atoi(e) : 0;
-    }
+    const int rs2_env = knob("DW_RS2", 0);
     if (rs2_env == 4 || rs2_env == 7 || rs2_env == 8) rs = rs2_env;
     else rs = (a.oh % 7 == 0 && a.oh <= 14) ? 7 : 4;  // taller strips measured slower (dw3 33.7 -> 37.1 us): not VALU-bound
   }

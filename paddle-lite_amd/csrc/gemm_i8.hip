@@ -879,11 +879,7 @@ int debug_read_stamps(void* dst, size_t bytes) {
 }
 
 static int gemm_variant() {  // PLHIP_GEMM_VARIANT: 0 auto, 1 private-tile kernel, 2 register-staged LDS kernel, 3 LDS-DMA ring, 5 wave-specialised
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PLHIP_GEMM_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
+  const int v = knob("GEMM_VARIANT", 0);
   return v;
 }
 
@@ -915,11 +911,7 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
     if (g.im_kw == 0 && g.XP > 0 && g.XP < g.HWX) g.HWX = g.XP;
     g.NT = (int)(((long)g.NB * ((g.HWX + 15) & ~15) + 127) / 128);  // 16-byte padded column space of this kernel
     const unsigned blocks = (unsigned)(((g.MT + 3) / 4) * (long)((g.NT + 7) / 8 * 8));
-    static int areg_env = -1;
-    if (areg_env < 0) {
-      const char* e = getenv("PLHIP_GEMM_AREG");
-      areg_env = e ? atoi(e) : 1;
-    }
+    const int areg_env = knob("GEMM_AREG", 1);
     const int ng = (areg_env && (g.KS & 3) == 0 && mfull && MA == 2) ? g.KS >> 2 : 0;
     const bool areg = ng == 1 || ng == 2 || ng == 4 || ng == 8;  // K = 128 / 256 / 512 / 1024
     const size_t lds = (size_t)(4 + 1) * (areg ? 4096 : 4096 + 4 * MA * 1024) + 4 * 2 * MA * 32 * 4 + 4 * STAMP_SLOTS * 8;
@@ -973,21 +965,14 @@ static void launch_gemm_t(const GemmArgs& g_in, bool vec_store, bool aligned, hi
     hipLaunchKernelGGL((gemm_i8_nchw_kernel<MA, OUT, false, false, true>), dim3(blocks), dim3(256), 0, s, g);
 }
 
-void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s) {
+// returns 0, or -3 when the shape exists on one kernel only and that kernel declines it (nothing is launched)
+int launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s) {
   if (!aligned_loads) vec_store = false;
   // The packed layout is a sequence of 32-row fragment tiles, so a layer packed for MA = 2 can also run with MA = 1
   // (32-row wave tiles): do so for M <= 128, where 64-row tiles would leave waves of the 4-wave block without work.
-  static int ma_env = -1;
-  if (ma_env < 0) {
-    const char* e = getenv("PLHIP_GEMM_MA");
-    ma_env = e ? atoi(e) : 0;
-  }
+  const int ma_env = knob("GEMM_MA", 0);
   GemmArgs g = g_in;
-  static int dbg_env = -1;
-  if (dbg_env < 0) {
-    const char* e = getenv("PLHIP_GEMM_DEBUG");
-    dbg_env = e ? atoi(e) : 0;
-  }
+  const int dbg_env = knob("GEMM_DEBUG", 0);
   g.dbg = dbg_env;
   // The transposed-read ring kernel (gemm_tr_i8.hip) is the implicit-GEMM engine (any M > 32, rows down to 7 columns).
   // For plain 1x1 / im2col GEMMs it is opt-in (PLHIP_GEMM_TR=2): measured on MobileNetV1's pointwise layers it ties
@@ -999,7 +984,7 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
   if (g.im_kw == 0 && gemm_variant() == 0 && (dbg_env & ~32) == 0) {
     GemmArgs t = g;
     if (t.XP > 0 && t.XP < t.HWX) t.HWX = t.XP;  // the TRUE row length of a dense slab
-    if (launch_gemm_wide(t, out, s)) return;
+    if (launch_gemm_wide(t, out, s)) return 0;
   }
   // (stride-2 / short-row implicit GEMMs exist on the transposed-read kernel ONLY: the timing bits of PLHIP_GEMM_DEBUG must
   // not send them to a first-generation kernel, which would read outside its operands: a GPU memory fault, seen once)
@@ -1007,7 +992,11 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
   if (g.M > 32 && (g.im_kw > 0 || (gemm_variant() == 0 && gemm_tr_enabled() >= 2)) && ((dbg_env & ~96) == 0 || tr_only)) {
     GemmArgs t = g;
     if (t.im_kw == 0 && t.XP > 0 && t.XP < t.HWX) t.HWX = t.XP;
-    if (launch_gemm_tr(t, out, s)) return;
+    if (launch_gemm_tr(t, out, s)) return 0;
+    // stride-2 / short-row implicit GEMMs exist on that kernel ONLY: the first-generation kernels would read outside their
+    // operands for these shapes.  conv_geom admits them under the same column-space bound launch_gemm_tr checks
+    // (plhip_capi.hip), so this is a defensive error, not a fallback
+    if (tr_only) return -3;
   }
   if (ma == 2 && ((ma_env == 0 && g.M <= 128 && g.M > 64) || (ma_env == 1 && g.im_kw == 0))) ma = 1;
   // 64-row tiles whose last tile is at most half full (M = 144: 192 rows computed and stored-checked for 144), and the
@@ -1025,6 +1014,7 @@ void launch_gemm_i8(const GemmArgs& g_in, int ma, int out, bool vec_store, bool 
     else if (out == OUT_F32) launch_gemm_t<2, OUT_F32>(g, vec_store, aligned_loads, s);
     else launch_gemm_t<2, OUT_I8>(g, vec_store, aligned_loads, s);
   }
+  return 0;
 }
 
 void launch_pack_weights(const int8_t* w, int8_t* wp, int G, int Mg, int Kg, int MT32, int KS, hipStream_t s) {
@@ -1186,11 +1176,7 @@ __global__ __launch_bounds__(256) void subsample2_1x1_i8_kernel(Im2colArgs a) {
 void launch_im2col(const Im2colArgs& a, hipStream_t s) {
   // rows = batch * G * Kg; Kg and batch*G ride on grid.y / grid.z (<= 65535 each, checked by the caller)
   const unsigned bg = (unsigned)(a.rows / (size_t)a.Kg);
-  static int sub_env = -1;
-  if (sub_env < 0) {
-    const char* e = getenv("PLHIP_SUBSAMPLE_1X1");  // 0 = the generic im2col kernel (A/B runs)
-    sub_env = e ? atoi(e) : 1;
-  }
+  const int sub_env = knob("SUBSAMPLE_1X1", 1);  // 0 = the generic im2col kernel (A/B runs)
   if (sub_env && a.kh == 1 && a.kw == 1 && a.pt == 0 && a.pl == 0 && a.sw == 2 && a.Kg == a.cin_g &&
       (a.oh - 1) * a.sh < a.h && (a.ow - 1) * 2 < a.w) {  // (no tap in a bottom / right padding)
     const size_t threads = a.rows * (size_t)((a.Np + 15) >> 4);

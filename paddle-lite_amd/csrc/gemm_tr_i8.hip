@@ -447,11 +447,7 @@ int debug_read_tr_stamps(void* dst, size_t bytes) {
 }
 
 int gemm_tr_enabled() {  // PLHIP_GEMM_TR=0: first-generation kernels only (A/B runs)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PLHIP_GEMM_TR");
-    v = e ? atoi(e) : 1;
-  }
+  const int v = knob("GEMM_TR", 1);
   return v;
 }
 
@@ -483,11 +479,7 @@ static void launch_tr_cfg(const GemmArgs& g, hipStream_t s) {
 bool launch_gemm_tr(const GemmArgs& g_in, int out, hipStream_t s) {
   GemmArgs g = g_in;
   {
-    static int delay_env = -1;
-    if (delay_env < 0) {
-      const char* e = getenv("PLHIP_TR_DELAY");
-      delay_env = e ? atoi(e) : 0;
-    }
+    const int delay_env = knob("TR_DELAY", 0);
     g.dbg = (g.dbg & 0xff) | (delay_env << 8);
   }
   // rows shorter than 16 bytes: only on the padded copy of the implicit route (a 16-byte piece may run past the row)
@@ -502,13 +494,9 @@ bool launch_gemm_tr(const GemmArgs& g_in, int out, hipStream_t s) {
     else if (out == OUT_F32) launch_tr_cfg<WN_, WM_, OUT_F32>(g, s);    \
     else launch_tr_cfg<WN_, WM_, OUT_I8>(g, s);                         \
   } while (0)
-  static int cfg_env = -1;
-  if (cfg_env < 0) {
-    // default 3: 4-wave blocks (128 x 256 / 256 x 128 tiles), two per CU, for every M (ResNet50's 3x3 layers: 5-8 % faster
+      // default 3: 4-wave blocks (128 x 256 / 256 x 128 tiles), two per CU, for every M (ResNet50's 3x3 layers: 5-8 % faster
     // than one 8-wave block per CU, whose waves read LDS together and multiply together); 0 = the 8-wave tiles
-    const char* e = getenv("PLHIP_TR_CFG");
-    cfg_env = e ? atoi(e) : 3;
-  }
+  const int cfg_env = knob("TR_CFG", 3);
   if (g.M > 128 && (cfg_env & 1)) PLHIP_TR_OUT(1, 4);
   else if (g.M > 128) PLHIP_TR_OUT(2, 4);
   else if (g.M > 64 && (cfg_env & 2)) PLHIP_TR_OUT(2, 2);

@@ -48,11 +48,7 @@ static int g_wide_ntt_override = -1;  // tests / A-B runs: plhip_debug_wide_ntt 
 void debug_set_wide_ntt(int v) { g_wide_ntt_override = v; }
 
 static int wide_env() {  // PLHIP_GEMM_WIDE: 1 (default) on, 0 = second-generation kernels only (A/B runs)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PLHIP_GEMM_WIDE");
-    v = e ? atoi(e) : 1;
-  }
+  const int v = knob("GEMM_WIDE", 1);
   return v;
 }
 
@@ -67,11 +63,7 @@ int gemm_wide_ntt(const GemmArgs& g) {
   const int CPI = (g.HWX + 15) >> 4;
   const long chunks = (long)g.NB * CPI;
   if (chunks * 16 >= ((long)1 << 31) - 4096) return 0;
-  static int force_env = -1;
-  if (force_env < 0) {
-    const char* e = getenv("PLHIP_WIDE_NTT");
-    force_env = e ? atoi(e) : 0;
-  }
+  const int force_env = knob("WIDE_NTT", 0);
   const int force = g_wide_ntt_override >= 0 ? g_wide_ntt_override : force_env;
   const int mblocks = (g.M + 255) / 256;
   int best = 0;
@@ -102,7 +94,7 @@ bool launch_gemm_wide(const GemmArgs& g_in, int out, hipStream_t s) {
   // layers, 128 -> 256 @28x28 38.7 vs 54.0 us, 1024 -> 1024 @7x7 30.2 vs 37.6: profiles/r03_final_opbench_f32_*.txt): this
   // kernel's row-per-lane 16-byte stores write 32 contiguous bytes per row and instruction, the ring kernels' epilogue 64.
   // It stays reachable for them through the tile override (tests, A/B runs).
-  if (out != OUT_I8 && g_wide_ntt_override < 0 && !getenv("PLHIP_WIDE_NTT")) return false;
+  if (out != OUT_I8 && g_wide_ntt_override < 0 && knob("WIDE_NTT", 0) == 0) return false;
   const int ntt = gemm_wide_ntt(g_in);
   if (!ntt) return false;
   GemmArgs g = g_in;

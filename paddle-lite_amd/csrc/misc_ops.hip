@@ -339,11 +339,7 @@ void launch_fc(const int8_t* x, const int8_t* wp, const float* scale, const floa
   // kernel below that stages x through LDS runs the network tails in half its time (m = 128, k = 1024, n = 1000: 8.8 vs
   // 18.7 us; 256 x 2048: 16.2 vs 30.9; 1024 x 1280: 22.3 vs 32.3): a lane of the MFMA form fetches its B operand from its own
   // x row (32 rows 1 KiB apart per load instruction).  PLHIP_FC_MFMA=1 selects it (parity test in a subprocess).
-  static int fc_mfma_env = -1;
-  if (fc_mfma_env < 0) {
-    const char* e = getenv("PLHIP_FC_MFMA");
-    fc_mfma_env = e ? atoi(e) : 0;
-  }
+  const int fc_mfma_env = knob("FC_MFMA", 0);
   const size_t lds_f = (size_t)FCF_MB * k > (size_t)4 * FCF_MB * 64 * 4 ? (size_t)FCF_MB * k : (size_t)4 * FCF_MB * 64 * 4;
   const bool fast_ok = (k & 15) == 0 && ((uintptr_t)x & 15) == 0 && lds_f <= 64 * 1024;
   if ((fc_mfma_env || !fast_ok) && (k & 31) == 0) {

@@ -52,13 +52,8 @@ struct ConvGeom {
   ConvImpl impl;  // a pure function of the descriptor, so that pack and run agree
 };
 
-static bool implicit_gemm_disabled() {  // PLHIP_IMPLICIT_GEMM=0: A/B runs against the im2col route
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PLHIP_IMPLICIT_GEMM");
-    v = (e && atoi(e) == 0) ? 1 : 0;
-  }
-  return v == 1;
+static bool implicit_gemm_disabled() {  // knob IMPLICIT_GEMM = 0: A/B runs against the im2col route
+  return plhip::knob("IMPLICIT_GEMM", 1) == 0;
 }
 // dims of the padded copy of the implicit-GEMM route: stride 1 the padded plane; stride 2 ONE of the 4 phase planes
 // (rows / columns 2y + p, 2x + q of the padded plane), its rows padded to a multiple of 4 columns
@@ -162,7 +157,7 @@ bool conv_geom(const plhip_conv_desc* d, ConvGeom* g) {
   if (g->impl == IMPL_IM2COL_GEMM && d->groups == 1 && (s1 || s2) && d->dil[0] == 1 && d->dil[1] == 1 && d->kw <= 11 &&
       d->kh * d->kw <= 121 && !implicit_gemm_disabled()) {
     const size_t padded = padded_input_bytes(d);
-    const bool fits = padded < ((size_t)1 << 31) - 4096 && (size_t)d->n * g->oh * rup(g->ow, 16) < ((size_t)1 << 31) - 256;
+    const bool fits = padded < ((size_t)1 << 31) - 4096 && (size_t)d->n * g->oh * rup(g->ow, 16) < ((size_t)1 << 31) - 1024;  // launch_gemm_tr's own bound (gemm_tr_i8.hip)
     if (plhip::gemm_tr_enabled()) {
       // transposed-read ring kernel: any M > 32, K >= 97, output rows down to 7 columns (one start-aligned 16-byte
       // chunk per row: the 14x14 and 7x7 planes of ResNet50's last stages), and stride 2 on a phase-split padded copy
@@ -509,7 +504,8 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     a.im_s = d->stride[0];
     a.res = t_res; a.res_relu = t_relu; a.y2 = t_y2; a.inv_scale2 = t_inv;
     const bool vec_store_i = (g.ow & 3) == 0 && aligned(y, 4 * esz_i) && aligned(t_res, 16) && aligned(t_y2, 4);
-    plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store_i, true, ctx->stream);
+    if (plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store_i, true, ctx->stream) != 0)
+      return fail(ctx, PLHIP_ERR_UNSUPPORTED, "conv2d: implicit GEMM outside the transposed-read kernel's column space");
     LAUNCHCHK(ctx, "gemm_i8_implicit");
     return PLHIP_OK;
   }
@@ -585,7 +581,8 @@ static plhip_status conv2d_impl(plhip_ctx* ctx, const plhip_conv_desc* d, const 
     a.alpha = d->act_alpha;
     a.im_kw = a.im_khkw = a.im_c = a.im_ph = a.im_pw = a.im_oh = 0;
     a.im_s = 1;
-    plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store, aligned_loads, ctx->stream);
+    if (plhip::launch_gemm_i8(a, g.MA, (int)out, vec_store, aligned_loads, ctx->stream) != 0)
+      return fail(ctx, PLHIP_ERR_UNSUPPORTED, "conv2d: GEMM shape outside every kernel");
     LAUNCHCHK(ctx, "gemm_i8");
   }
   return PLHIP_OK;
@@ -903,10 +900,29 @@ extern "C" int plhip_debug_read_fw_stamps(void* dst_host, size_t bytes) {
   if (!dst_host) return -1;
   return plhip::debug_read_fw_stamps(dst_host, bytes);
 }
-// Diagnostics switch of the shipped library (not part of the operator ABI; declared in include/plhip.h so that nothing in
-// the library's behaviour depends on the environment): key = "fused_stamps" -> in-kernel timeline of the fused kernel
+// Diagnostics switches of the shipped library (declared in include/plhip.h).  NOTHING in the library reads the environment:
+// the A/B and timing knobs the kernels' launchers consult (plhip::knob) live in this table and change only
+// through plhip_debug_set; an unknown key is refused.  "fused_stamps" / "fused_exp": the fused kernel's timeline / timing experiments.
+namespace plhip {
+namespace {
+struct Knob { const char* name; int value; bool set; };
+Knob g_knobs[] = {
+    {"STEM_MFMA", 0, false}, {"CONV_PATCH", 0, false}, {"CONV_PATCH_S2", 0, false}, {"PATCH_DEBUG", 0, false}, {"PATCH_DELAY", 0, false},
+    {"STEM7", 0, false}, {"DW_STAGE", 0, false}, {"DW_STAGE_NP2", 0, false}, {"DW_FASTV", 0, false}, {"DW5_DIRECT", 0, false},
+    {"DW_RS1", 0, false}, {"DW_RS2", 0, false}, {"GEMM_VARIANT", 0, false}, {"GEMM_AREG", 0, false}, {"GEMM_MA", 0, false},
+    {"GEMM_DEBUG", 0, false}, {"SUBSAMPLE_1X1", 0, false}, {"GEMM_TR", 0, false}, {"TR_DELAY", 0, false}, {"TR_CFG", 0, false},
+    {"GEMM_WIDE", 0, false}, {"WIDE_NTT", 0, false}, {"FC_MFMA", 0, false}, {"IMPLICIT_GEMM", 0, false}};
+}  // namespace
+int knob(const char* name, int dflt) {
+  for (const Knob& k : g_knobs)
+    if (!strcmp(k.name, name)) return k.set ? k.value : dflt;
+  return dflt;
+}
+}  // namespace plhip
 extern "C" int plhip_debug_set(const char* key, int value) {
   if (!key) return -1;
+  for (plhip::Knob& k : plhip::g_knobs)
+    if (!strcmp(k.name, key)) { k.value = value; k.set = true; return 0; }
   static int fused_bits = 0;
   if (!strcmp(key, "fused_stamps")) { fused_bits = (fused_bits & ~32) | (value ? 32 : 0); plhip::debug_set_fused(fused_bits); return 0; }
   if (!strcmp(key, "fused_exp")) { fused_bits = (fused_bits & ~31) | (value & 31); plhip::debug_set_fused(fused_bits); return 0; }  // timing experiments, wrong results

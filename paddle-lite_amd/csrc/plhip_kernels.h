@@ -6,6 +6,10 @@
 
 namespace plhip {
 
+// A/B and timing knobs of the launchers: name -> value set through plhip_debug_set (include/plhip.h), else the
+// default.  The library never reads the environment.
+int knob(const char* name, int dflt);
+
 struct GemmArgs {
   const int8_t* wp;    // packed weights of this group: [MT32][KS][64][16]
   const int8_t* x;     // B operand base for this group: row k of image b at x + b*x_bstride + k*HWX
@@ -167,7 +171,7 @@ void launch_fused_dwpw(const FusedArgs& a, int out, hipStream_t s);
 void debug_set_fused(int v);                        // bit 5 (32): timeline stamps
 int debug_read_fw_stamps(void* dst, size_t bytes);
 
-void launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);
+int launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);  // 0 or -3
 // second-generation ring kernel (gemm_tr_i8.hip); false = shape outside it, the caller falls back
 bool launch_gemm_tr(const GemmArgs& g, int out, hipStream_t s);
 int gemm_tr_enabled();

@@ -3,6 +3,7 @@
 
 #include <string.h>
 
+#include "lite/core/mir/fusion/hip_conv_tail_matcher.h"
 #include "plhip.h"
 
 #include <cstdio>
@@ -134,55 +135,42 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
     }
     return n;
   };
-  auto producer = [&](const std::string& v) {
-    for (size_t i = 0; i < st.size(); ++i)
-      if (!dead[i] && (st[i].out == v || (!st[i].calib_out.empty() && st[i].calib_out == v))) return static_cast<int>(i);
-    return -1;
-  };
-  auto is_f32_conv = [&](int i) {
-    return i >= 0 && st[i].kind == "op" && ops_[st[i].op].type == "conv2d" && ops_[st[i].op].enable_int8 && !st[i].int8_out &&
-           st[i].calib_out.empty() && !st[i].drop_f32;
-  };
-  // (A) elementwise_add (+relu) into the LATER of its fp32 conv producers, when that conv's output feeds only the add
-  for (size_t i = 0; i < st.size(); ++i) {
-    if (dead[i] || st[i].kind != "op") continue;
-    const GraphOp& op = ops_[st[i].op];
-    const bool plain = op.type == "elementwise_add", relu = op.type == "fusion_elementwise_add_activation" && op.act_type == "relu";
-    if (!plain && !relu) continue;
-    const int pa = producer(st[i].op_inputs[0]), pb = producer(st[i].op_inputs[1]);
-    int conv = -1, other = -1;
-    if (is_f32_conv(pb) && pb > pa && st[pb].res.empty() && uses(st[pb].out) == 1) conv = pb, other = 0;
-    else if (is_f32_conv(pa) && pa > pb && st[pa].res.empty() && uses(st[pa].out) == 1) conv = pa, other = 1;
-    if (conv < 0) continue;
-    st[conv].res = st[i].op_inputs[other];
-    st[conv].res_relu = relu;
-    st[conv].out = st[i].out;  // the conv now writes the sum
-    dead[i] = true;
-  }
-  // (C) conv[fp32_out] -> pool2d(max) -> calib: quantise in the conv, pool in int8
-  for (size_t i = 0; i < st.size(); ++i) {
-    if (dead[i] || st[i].kind != "calib_f2i") continue;
-    const int pp = producer(st[i].in);
-    if (pp < 0 || st[pp].kind != "op" || ops_[st[pp].op].type != "pool2d" || ops_[st[pp].op].pooling_type != "max") continue;
-    const int pc = producer(st[pp].op_inputs[0]);
-    if (!is_f32_conv(pc) || uses(st[pc].out) != 1 || uses(st[pp].out) != 1) continue;
-    st[pc].calib_out = st[pc].out + "/precision_trans";
-    st[pc].calib_scale = st[i].scale;
-    st[pc].drop_f32 = true;
-    st[pp].op_inputs[0] = st[pc].calib_out;
-    st[pp].out = st[i].out;
-    st[pp].pool_int8 = true;
-    dead[i] = true;
-  }
-  // (B) calib[fp32_to_int8] into the fp32 conv (possibly already carrying an add) that produces its input
-  for (size_t i = 0; i < st.size(); ++i) {
-    if (dead[i] || st[i].kind != "calib_f2i") continue;
-    const int pc = producer(st[i].in);
-    if (!is_f32_conv(pc) || st[pc].out != st[i].in) continue;
-    st[pc].calib_out = st[i].out;
-    st[pc].calib_scale = st[i].scale;
-    dead[i] = true;
-    st[pc].drop_f32 = uses(st[pc].out) == 0;
+  // (A) (C) (B): the conv-tail patterns, matched by the SAME code a Paddle-Lite tree runs as a mir pass
+  // (lite/core/mir/fusion/hip_conv_tail_matcher.h; patches/0006 carries it with its SSAGraph adapter)
+  {
+    using mir::fusion::TailInst;
+    std::vector<TailInst> prog(st.size());
+    for (size_t i = 0; i < st.size(); ++i) {
+      TailInst& t = prog[i];
+      t.output = st[i].out;
+      if (st[i].kind == "op") {
+        const GraphOp& op = ops_[st[i].op];
+        t.inputs = st[i].op_inputs;
+        if (op.type == "conv2d" && op.enable_int8 && !st[i].int8_out) t.kind = TailInst::kConvF32;
+        else if (op.type == "elementwise_add") t.kind = TailInst::kAdd;
+        else if (op.type == "fusion_elementwise_add_activation" && op.act_type == "relu") t.kind = TailInst::kAddRelu;
+        else if (op.type == "pool2d" && op.pooling_type == "max") t.kind = TailInst::kMaxPool;
+      } else {
+        t.inputs = {st[i].in};
+        if (st[i].kind == "calib_f2i") {
+          t.kind = TailInst::kCalibF2I;
+          t.calib_scale = st[i].scale;
+        }
+      }
+    }
+    mir::fusion::MatchConvTails(&prog);
+    for (size_t i = 0; i < st.size(); ++i) {
+      const TailInst& t = prog[i];
+      dead[i] = t.dead;
+      st[i].out = t.output;
+      if (st[i].kind == "op") st[i].op_inputs = t.inputs;
+      st[i].res = t.residual;
+      st[i].res_relu = t.residual_relu;
+      st[i].calib_out = t.calib_out;
+      if (!t.calib_out.empty()) st[i].calib_scale = t.fused_calib_scale;
+      st[i].drop_f32 = t.drop_f32;
+      st[i].pool_int8 = t.pool_int8;
+    }
   }
   // (D) depthwise_conv2d[int8_out] whose only consumer is a plain 1x1 conv (no tail of its own) takes it over.  Mode 2 (default):
   // only where the fused kernel takes the pair, which needs the depthwise conv's input shape: propagated from the feeds through

@@ -47,11 +47,57 @@ void ConvCompute<Ptype, OutType>::BuildDesc() {
   desc_.groups = param.groups;
 }
 
+// Weights: pre-pack once per IMPLEMENTATION (trans_gemm_weights<kInt8> -> prepackA_int8 analogue), or keep OIHW for depthwise.
+// The implementation plhip's conv_geom picks — and with it the packed layout — depends on the input shape (the patch kernels
+// need a row pitch of 8..64, the 7x7 stem OW % 4 == 0 ...): ReInitWhenNeeded calls this again when a resized feed changes it.
+template <PrecisionType Ptype, PrecisionType OutType>
+void ConvCompute<Ptype, OutType>::PackWeights() {
+  auto& param = this->template Param<param_t>();
+  auto& ctx = this->ctx_->template As<HIPContext>();
+  // One packed device copy per process and device (packed_weight_cache.h): predictors that run the same model — the three
+  // in flight of bench.py, a serving process with a predictor per thread (cxx_api.h:103-137) — share it; host-resident
+  // weights are the key (persistable params of a model; weights already on the device are packed privately).
+  const size_t w_bytes = static_cast<size_t>(param.filter->numel());
+  const size_t packed = is_depthwise_ ? w_bytes : plhip_conv_packed_weight_bytes(&desc_);
+  CHECK_GT(packed, 0UL) << "invalid conv configuration";
+  auto pack_into = [&](void* d) {
+    Tensor staged;
+    const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(param.filter, &staged, w_bytes));
+    if (is_depthwise_) {
+      ctx.MemcpySync(d, w_dev, w_bytes, IoDirection::DtoD);
+    } else {
+      HIP_CALL(ctx.ctx(), plhip_pack_conv_weights(ctx.ctx(), &desc_, w_dev, d));
+    }
+    ctx.Sync();  // the bytes are final (and `staged` may die) before anybody else sees them
+  };
+  if (param.filter->target() == TARGET(kHost)) {
+    const auto wd = param.filter->dims();
+    std::string layout = is_depthwise_ ? std::string("dw_oihw") : std::string(plhip_conv_impl_name(&desc_));
+    for (size_t i = 0; i < wd.size(); ++i) layout += "_" + std::to_string(wd[i]);
+    layout += "_g" + std::to_string(desc_.groups) + "_w" + std::to_string(desc_.w) + "_p" + std::to_string(desc_.pad[2]) + "_" + std::to_string(desc_.pad[3]);
+    packed_owner_ = PackedWeightCache::Global().GetOrPack(static_cast<int>(TargetWrapperHip::GetCurDevice()), layout, param.filter->raw_data(), w_bytes, packed, pack_into);
+    weights_.ShareDataWith(*packed_owner_);
+  } else {
+    pack_into(weights_.mutable_data(TARGET(kHIP), packed));
+  }
+  packed_impl_ = is_depthwise_ ? std::string("dw_oihw") : std::string(plhip_conv_impl_name(&desc_));
+  packed_bytes_ = packed;
+}
+
 template <PrecisionType Ptype, PrecisionType OutType>
 void ConvCompute<Ptype, OutType>::ReInitWhenNeeded() {
   auto& param = this->template Param<param_t>();
   if (last_shape_ == param.x->dims()) return;  // conv_gemmlike.cc:92 idiom
   BuildDesc();
+  if (!is_depthwise_ && packed_bytes_ != 0) {
+    // a resized feed may cross an implementation boundary (3x3 64 -> 64 from W = 56 to W = 112: patch kernel -> implicit GEMM;
+    // the ResNet stem from 224 to 226): the packed bytes belong to ONE implementation, so pack again for the new one
+    // (through the shared cache: a layout seen before is reused) instead of running it on the old layout
+    if (packed_impl_ != plhip_conv_impl_name(&desc_) || packed_bytes_ != plhip_conv_packed_weight_bytes(&desc_)) {
+      PackWeights();
+      kernel_func_name_ = std::string(plhip_conv_impl_name(&desc_));
+    }
+  }
   workspace_bytes_ = is_depthwise_ ? 0 : plhip_conv_workspace_bytes(&desc_);
   if (has_pw_) {  // the pointwise conv sees the depthwise conv's output plane
     const auto od = param.output->dims();
@@ -185,33 +231,7 @@ void ConvCompute<Ptype, OutType>::PrepareForRun() {
   if (kInt8Out && desc_.act == PLHIP_ACT_RELU6) act_alpha_ = act_alpha_ / out_scale;  // conv_gemmlike.cc:259-263
   desc_.act_alpha = act_alpha_;
 
-  // ---- weights: pre-pack once (trans_gemm_weights<kInt8> -> prepackA_int8 analogue), or keep OIHW for depthwise
-  // One packed device copy per process and device (packed_weight_cache.h): predictors that run the same model — the three
-  // in flight of bench.py, a serving process with a predictor per thread (cxx_api.h:103-137) — share it; host-resident
-  // weights are the key (persistable params of a model; weights already on the device are packed privately).
-  const size_t w_bytes = static_cast<size_t>(param.filter->numel());
-  const size_t packed = is_depthwise_ ? w_bytes : plhip_conv_packed_weight_bytes(&desc_);
-  CHECK_GT(packed, 0UL) << "invalid conv configuration";
-  auto pack_into = [&](void* d) {
-    Tensor staged;
-    const int8_t* w_dev = static_cast<const int8_t*>(DeviceCopyOf(param.filter, &staged, w_bytes));
-    if (is_depthwise_) {
-      ctx.MemcpySync(d, w_dev, w_bytes, IoDirection::DtoD);
-    } else {
-      HIP_CALL(ctx.ctx(), plhip_pack_conv_weights(ctx.ctx(), &desc_, w_dev, d));
-    }
-    ctx.Sync();  // the bytes are final (and `staged` may die) before anybody else sees them
-  };
-  if (param.filter->target() == TARGET(kHost)) {
-    const auto wd = param.filter->dims();
-    std::string layout = is_depthwise_ ? std::string("dw_oihw") : std::string(plhip_conv_impl_name(&desc_));
-    for (size_t i = 0; i < wd.size(); ++i) layout += "_" + std::to_string(wd[i]);
-    layout += "_g" + std::to_string(desc_.groups) + "_w" + std::to_string(desc_.w) + "_p" + std::to_string(desc_.pad[2]) + "_" + std::to_string(desc_.pad[3]);
-    packed_owner_ = PackedWeightCache::Global().GetOrPack(static_cast<int>(TargetWrapperHip::GetCurDevice()), layout, param.filter->raw_data(), w_bytes, packed, pack_into);
-    weights_.ShareDataWith(*packed_owner_);
-  } else {
-    pack_into(weights_.mutable_data(TARGET(kHIP), packed));
-  }
+  PackWeights();
   kernel_func_name_ = is_depthwise_ ? std::string("conv_depthwise_") + std::to_string(desc_.kh) + "x" + std::to_string(desc_.kw) +
                                           (kInt8Out ? "_int8_int8_hip" : "_int8_fp32_hip")
                                     : std::string(plhip_conv_impl_name(&desc_));

@@ -34,6 +34,9 @@ class ConvCompute : public KernelLite<TARGET(kHIP), Ptype>, public HipFusableKer
   bool is_depthwise_{false};
   DDim last_shape_;
   Tensor weights_;   // packed (GEMM path) or raw OIHW (depthwise path), on device
+  void PackWeights();
+  std::string packed_impl_;   // the implementation the weights are packed for, and their size: checked on every reshape
+  size_t packed_bytes_{0};
   std::shared_ptr<Tensor> packed_owner_;  // the process-wide shared copy weights_ aliases (packed_weight_cache.h), if any
   Tensor scale_;     // folded per-channel scale, device
   Tensor bias_;      // folded bias, device (only if param.bias)

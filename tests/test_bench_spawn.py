@@ -41,6 +41,20 @@ def test_strong_scaling_ragged_global_batch_three_ranks():
     assert "MobileNetV2" in line["metric"]
 
 
+def test_eight_ranks_strong_scaling_ragged_shards():
+    """The driver's N = 8 point of BASELINE config C5 (`bench.py --config c5 --gpus 8`: strong scaling by default), rehearsed on
+    the CPU with gloo: 8 rank processes, a global batch that does NOT divide by 8 (1021 -> shards of 128 x 5 + 127 x 3),
+    network broadcast, scatter, one gather per step in rank-major order (checked inside bench.py), ONE JSON line."""
+    rc, out, err = _run(["--gpus", "8", "--steps", "5", "--warmup", "2", "--inflight", "2", "--config", "c5", "--global-batch", "1021",
+                         "--res", "32", "--windows", "2"], timeout=600)
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["global_batch"] == 1021
+    assert line["config"]["parallelism"].startswith("batch split x8") and line["value"] > 0 and "MobileNetV2" in line["metric"]
+
+
 def test_world_size_mismatch_is_an_error():
     rc, out, err = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc == 2 and "WORLD_SIZE=2" in err and out.strip() == ""

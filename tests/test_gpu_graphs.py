@@ -247,6 +247,14 @@ def test_mobilenet_v2_at_the_benchmark_batch_1024(lite, wl, plref):
     assert n_i8 >= 30 and n_f32 >= 2
 
 
+def test_mobilenet_v2_at_the_per_rank_shard_of_an_8_gpu_run(lite, wl, plref):
+    """BASELINE config C5 on 8 GPUs: 1024 images split by shard_range = 128 per rank (`bench.py --config c5 --gpus 8` runs
+    exactly this program on every rank): the grid sizes, tile maps and XCD shares of THAT batch, prefix == the batch-2 run,
+    one mid-batch image == the oracle."""
+    n_i8, n_f32 = _big_batch_check(lite, wl, plref, wl.mobilenet_v2_net(), 128, 322, fuse=True, mid=77)
+    assert n_i8 >= 30 and n_f32 >= 2
+
+
 def test_pointwise_7x7_rows_at_the_end_of_an_allocation(gpu_ctx, plref, pkg):
     """HW = 49 rows are not a multiple of 4 bytes: the ring kernel's END-aligned 16-byte pieces must use the true row
     length (round 1 passed the length rounded up to 4 and read 3 bytes past the last row).  pw13's shape at batch 128:

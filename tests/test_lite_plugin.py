@@ -112,6 +112,48 @@ def test_conv_kernel_classes_vs_oracle(lite, plref):
 
 
 @pytest.mark.gpu
+def test_feed_resize_across_an_implementation_boundary_repacks_the_weights(lite, plref):
+    """The conv implementation — and with it the packed weight layout — depends on the input shape: a dense 3x3 64 -> 64
+    runs on the patch kernel at W = 56 (row pitch 64) and on the implicit GEMM at W = 112; the 7x7 stride-2 stem runs on its
+    direct kernel when OW % 4 == 0 and on the implicit GEMM otherwise.  A predictor whose feed is resized across such a
+    boundary (AddFeed on the existing name) must repack (ConvCompute::ReInitWhenNeeded -> PackWeights) — running the new
+    implementation on the old layout would return wrong numbers with no fault.  Every shape is compared with the oracle, and
+    going BACK to the first shape must reproduce the first result."""
+    rng = np.random.default_rng(201)
+    for (cin, cout, k, s, pad, sizes, want_impls) in [
+            (64, 64, 3, 1, 1, (56, 112, 56, 30), ("conv_patch", "conv_implicit_gemm", "conv_patch", "conv_patch")),
+            (3, 64, 7, 2, 3, (224, 226, 224), ("conv_7x7s2_direct", "conv_implicit_gemm", "conv_7x7s2_direct"))]:
+        w = rng.integers(-127, 128, (cout, cin, k, k)).astype(np.int8)
+        bias = rng.uniform(-1, 1, cout).astype(np.float32)
+        w_scale = ((1 + np.arange(cout) % 7) / 127.0 / 4.0).astype(np.float32)
+        in_scale, out_scale = 1 / 127.0, cin * k * k / 127.0 / 4
+        p = lite.Predictor(0)
+        try:
+            first = None
+            for i, (hw, impl) in enumerate(zip(sizes, want_impls)):
+                x = rng.integers(-127, 128, (2, cin, hw, hw)).astype(np.int8) if i != 2 else first[0]
+                p.add_feed("x", x.shape, lite.PREC_INT8)
+                if i == 0:
+                    p.add_io_copy("x", "xd", True)
+                    p.add_conv("conv2d", "xd", "yd", w, bias, (s, s), (pad,) * 4, (1, 1), 1, 1, 0.0, in_scale, w_scale, out_scale, True)
+                    p.add_io_copy("yd", "y", False)
+                p.set_input("x", x)
+                p.run()
+                y = p.get_var("y", np.int8)
+                sh = plref.shape(2, cin, hw, hw, cout, k, k, (pad,) * 4, (s, s), (1, 1), 1)
+                y_ref, _ = plref.conv2d(sh, x, w, bias, in_scale, w_scale, out_scale, 1, 0.0, True, via_gemm=True)
+                assert y.shape == y_ref.shape and np.array_equal(y, y_ref), (cin, cout, k, hw, int((y != y_ref).sum()))
+                name = p.time_instruction(1, 1)[2]  # the kernel the conv instruction ran (KernelBase::SetProfileRuntimeKernelInfo)
+                assert name.startswith(impl), (hw, name, impl)
+                if i == 0:
+                    first = (x, y)
+                if i == 2:
+                    assert np.array_equal(y, first[1])
+        finally:
+            p.close()
+
+
+@pytest.mark.gpu
 def test_bad_weight_scale_is_fatal(lite):
     """weights scale size must equal filter number or 1 (conv_gemmlike.cc:213-215) -> LOG(FATAL)."""
     p = lite.Predictor(0)

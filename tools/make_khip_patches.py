@@ -20,6 +20,10 @@ HIP_MEMCPY = '''  } else if (type == TargetType::kHIP) {
 #endif
 '''
 
+PASS_H = '// hip_conv_tail_fuse_pass.h — kHIP graph-level conv-tail fusions as a mir pass (see hip_conv_tail_matcher.h).\n#pragma once\n\n#include <memory>\n#include "lite/core/mir/pass.h"\n\nnamespace paddle {\nnamespace lite {\nnamespace mir {\n\nclass HipConvTailFusePass : public ProgramPass {\n public:\n  void Apply(const std::unique_ptr<SSAGraph>& graph) override;\n};\n\n}  // namespace mir\n}  // namespace lite\n}  // namespace paddle\n'
+
+PASS_CC = '// hip_conv_tail_fuse_pass.cc — SSAGraph adapter of the kHIP conv-tail matcher.\n//\n// Runs behind type_precision_cast_pass / type_layout_cast_pass (the calib statements exist, every statement has its picked\n// kernel) and in front of runtime_context_assign_pass.  It lists the statements in topological order for\n// fusion::MatchConvTails, then applies its decisions the way lite/core/mir/fusion/conv_elementwise_fuser.cc applies its\n// own: the surviving conv statement gets the residual operand through the reference\'s ConvParam::residualData\n// (op input "ResidualData" + attribute fuse_residual_connection, lite/operators/conv_op.h:102), its output variable is\n// re-linked, the fused statements are removed with GraphSafeRemoveNodes, and the picked kHIP kernel receives the state the\n// reference has no field for (relu behind the add, the int8 calib copy, the dropped fp32 output) through\n// kernels::hip::HipFusableKernel::SetFusion (lite/kernels/hip/conv_fusion.h).\n#include "lite/core/mir/fusion/hip_conv_tail_fuse_pass.h"\n#include <map>\n#include <set>\n#include <string>\n#include <vector>\n#include "lite/core/mir/fusion/hip_conv_tail_matcher.h"\n#include "lite/core/mir/pass_registry.h"\n#include "lite/core/mir/pattern_matcher.h"\n#include "lite/kernels/hip/conv_fusion.h"\n\nnamespace paddle {\nnamespace lite {\nnamespace mir {\n\nnamespace {\n\nstd::string first_arg(const OpInfo* info, const std::string& slot, bool input) {\n  const auto& names = input ? info->Input(slot) : info->Output(slot);\n  return names.empty() ? std::string() : names.front();\n}\n\n// one statement as the matcher sees it\nfusion::TailInst Describe(Node* n) {\n  fusion::TailInst t;\n  auto& stmt = n->AsStmt();\n  const OpInfo* info = stmt.op_info();\n  const std::string type = stmt.op_type();\n  auto& kernel = stmt.picked_kernel();\n  const bool hip = kernel.target() == TARGET(kHIP);\n  if (type == "conv2d" && hip && kernel.precision() == PRECISION(kInt8) && kernel.alias() == "fp32_out") {\n    t.kind = fusion::TailInst::kConvF32;\n    t.inputs = {first_arg(info, "Input", true)};\n    t.output = first_arg(info, "Output", false);\n  } else if ((type == "elementwise_add" || type == "fusion_elementwise_add_activation") && hip) {\n    const bool relu = type == "fusion_elementwise_add_activation" && info->GetAttr<std::string>("act_type") == "relu";\n    t.kind = type == "elementwise_add" ? fusion::TailInst::kAdd : (relu ? fusion::TailInst::kAddRelu : fusion::TailInst::kOther);\n    t.inputs = {first_arg(info, "X", true), first_arg(info, "Y", true)};\n    t.output = first_arg(info, "Out", false);\n  } else if (type == "pool2d" && hip && info->GetAttr<std::string>("pooling_type") == "max") {\n    t.kind = fusion::TailInst::kMaxPool;\n    t.inputs = {first_arg(info, "X", true)};\n    t.output = first_arg(info, "Out", false);\n  } else if (type == "calib" && hip && kernel.alias() == "fp32_to_int8") {\n    t.kind = fusion::TailInst::kCalibF2I;\n    t.inputs = {first_arg(info, "Input", true)};\n    t.output = first_arg(info, "Out", false);\n    t.calib_scale = info->GetAttr<float>("scale");\n  } else {  // every other statement only counts as a reader / writer of its variables\n    for (auto* in : n->inlinks) t.inputs.push_back(in->AsArg().name);\n    t.output = n->outlinks.empty() ? std::string() : n->outlinks.front()->AsArg().name;\n  }\n  return t;\n}\n\n// ResetOp creates the statement\'s kernels again for every valid place: keep the one this pass wants (static_kernel_pick_pass has\n// run already and will not run again)\nvoid Repick(Node::Stmt* stmt, PrecisionType precision, const std::string& alias) {\n  std::vector<std::unique_ptr<KernelBase>> keep;\n  for (auto& k : stmt->kernels()) {\n    if (k->target() == TARGET(kHIP) && k->precision() == precision && k->alias() == alias) {\n      keep.emplace_back(std::move(k));\n      break;\n    }\n  }\n  CHECK(!keep.empty()) << stmt->op_type() << ": no kHIP kernel " << alias;\n  stmt->SetKernels(std::move(keep));\n}\n\n}  // namespace\n\nvoid HipConvTailFusePass::Apply(const std::unique_ptr<SSAGraph>& graph) {\n  std::vector<Node*> order = graph->StmtTopologicalOrder();\n  std::vector<fusion::TailInst> before, prog;\n  for (auto* n : order) before.push_back(Describe(n));\n  prog = before;\n  fusion::MatchConvTails(&prog);\n\n  std::set<const Node*> dead;\n  for (size_t i = 0; i < order.size(); ++i) {\n    Node* n = order[i];\n    const fusion::TailInst& t = prog[i];\n    if (t.dead) {\n      dead.insert(n);\n      continue;\n    }\n    auto& stmt = n->AsStmt();\n    if (t.kind == fusion::TailInst::kMaxPool && t.pool_int8) {\n      // pool2d(max) moved behind the quantiser: reads the conv\'s int8 copy, writes the former calib output; the int8 kernel is\n      // picked again from the valid places (pool2d kHIP kInt8 def)\n      cpp::OpDesc desc = *stmt.mutable_op_info();\n      desc.SetInput("X", {t.inputs[0]});\n      desc.SetOutput("Out", {t.output});\n      stmt.ResetOp(desc, graph->valid_places());\n      Repick(&stmt, PRECISION(kInt8), "def");\n      for (auto* in : std::vector<Node*>(n->inlinks.begin(), n->inlinks.end())) RemoveDirectedLink(in, n);\n      for (auto* out : std::vector<Node*>(n->outlinks.begin(), n->outlinks.end())) RemoveDirectedLink(n, out);\n      IR_NODE_LINK_TO(graph->RetrieveArgument(t.inputs[0]) ? graph->RetrieveArgument(t.inputs[0]) : graph->NewArgumentNode(t.inputs[0]), n);\n      IR_OP_VAR_LINK(n, graph->RetrieveArgument(t.output));\n      continue;\n    }\n    if (t.kind != fusion::TailInst::kConvF32 || (t.residual.empty() && t.calib_out.empty())) continue;\n    // ---- the surviving conv\n    cpp::OpDesc desc = *stmt.mutable_op_info();\n    auto* scope = stmt.op()->scope();\n    if (!t.residual.empty()) {\n      desc.SetInput("ResidualData", {t.residual});\n      desc.SetAttr("fuse_residual_connection", true);\n      IR_NODE_LINK_TO(graph->RetrieveArgument(t.residual), n);\n    }\n    if (t.output != before[i].output) {  // the conv writes the sum now\n      desc.SetOutput("Output", {t.output});\n      for (auto* out : std::vector<Node*>(n->outlinks.begin(), n->outlinks.end())) {\n        RemoveDirectedLink(n, out);\n        dead.insert(out);  // the conv\'s old output variable has no reader left\n      }\n      IR_OP_VAR_LINK(n, graph->RetrieveArgument(t.output));\n    }\n    stmt.ResetOp(desc, graph->valid_places());  // re-attaches the param (residualData)\n    Repick(&stmt, PRECISION(kInt8), "fp32_out");\n    kernels::hip::HipConvFusion f;\n    f.fuse_residual_relu = t.residual_relu;\n    if (!t.calib_out.empty()) {\n      Node* q = graph->RetrieveArgument(t.calib_out);\n      if (!q) q = graph->NewArgumentNode(t.calib_out);  // pattern (C): "<conv out>/precision_trans" is new\n      IR_OP_VAR_LINK(n, q);\n      f.calib_output = scope->Var(t.calib_out)->GetMutable<lite::Tensor>();\n      f.calib_scale = t.fused_calib_scale;\n      f.drop_fp32_output = t.drop_f32;\n    }\n    auto* fusable = dynamic_cast<kernels::hip::HipFusableKernel*>(&stmt.picked_kernel());\n    CHECK(fusable) << "conv2d kHIP kInt8 fp32_out must implement HipFusableKernel";\n    fusable->SetFusion(f);\n  }\n  GraphSafeRemoveNodes(graph.get(), dead);\n}\n\n}  // namespace mir\n}  // namespace lite\n}  // namespace paddle\n\nREGISTER_MIR_PASS(hip_conv_tail_fuse_pass, paddle::lite::mir::HipConvTailFusePass).BindTargets({TARGET(kHIP)});\n'
+
 EDITS = {
     "0001-place-add-kHIP-target.patch": {
         "lite/api/paddle_place.h": [
@@ -137,10 +141,29 @@ EDITS = {
             ("add_subdirectory(cuda)\n", "add_subdirectory(cuda)\nadd_subdirectory(hip)\n"),
         ],
     },
+    "0006-mir-hip-conv-tail-fuse-pass.patch": {
+        "lite/core/optimizer.h": [
+            ("         \"runtime_context_assign_pass\",\n         \"argument_type_display_pass\",\n         \"lite_reshape_fuse_pass\",",
+             "         \"hip_conv_tail_fuse_pass\",  // kHIP: conv + residual add (+relu) + calib, conv + max pool + calib\n"
+             "         \"runtime_context_assign_pass\",\n         \"argument_type_display_pass\",\n         \"lite_reshape_fuse_pass\","),
+        ],
+        "lite/api/paddle_use_passes.h": [
+            ("USE_MIR_PASS(lite_conv_elementwise_fuse_pass);\n", "USE_MIR_PASS(lite_conv_elementwise_fuse_pass);\nUSE_MIR_PASS(hip_conv_tail_fuse_pass);\n"),
+        ],
+        "lite/core/mir/CMakeLists.txt": [
+            ("      fusion/conv_elementwise_fuse_pass.cc\n", "      fusion/conv_elementwise_fuse_pass.cc\n      fusion/hip_conv_tail_fuse_pass.cc\n"),
+        ],
+    },
 }
 
 
 NEW_FILES = {
+    "0006-mir-hip-conv-tail-fuse-pass.patch": {
+        # the matcher is THIS repository's file, verbatim (tests/test_patches.py compares the bytes)
+        "lite/core/mir/fusion/hip_conv_tail_matcher.h": open(os.path.join(ROOT, "paddle-lite_amd", "lite", "core", "mir", "fusion", "hip_conv_tail_matcher.h")).read(),
+        "lite/core/mir/fusion/hip_conv_tail_fuse_pass.h": PASS_H,
+        "lite/core/mir/fusion/hip_conv_tail_fuse_pass.cc": PASS_CC,
+    },
     "0005-runtime-sync-hooks-copysync-kernel-list-and-cmake-for-kHIP.patch": {
         "lite/kernels/hip/CMakeLists.txt":
             "if((NOT LITE_ON_MODEL_OPTIMIZE_TOOL) AND (NOT LITE_WITH_PYTHON) AND (NOT LITE_WITH_HIP))\n    return()\nendif()\n\n"
