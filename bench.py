@@ -362,8 +362,10 @@ def main():
     import queue
     import threading
     import __graft_entry__ as ge
-    ge.import_package()
+    pkg_ = ge.import_package()
     lite = importlib.import_module("paddle_lite_amd.liteapi")
+    if not dry:
+        pkg_.capi.load()  # the same libplhip.so the predictor library links: forwards PLHIP_<KNOB> diagnostics (printed as debug_knobs)
     wl = importlib.import_module("paddle_lite_amd.workloads")
     sharding = importlib.import_module("paddle_lite_amd.sharding")
 

@@ -73,7 +73,7 @@ _lib = None
 # bench.py prints the dict in its JSON line, so a measurement taken with a knob says so.
 KNOBS = ("STEM_MFMA", "CONV_PATCH", "CONV_PATCH_S2", "PATCH_DEBUG", "PATCH_DELAY", "STEM7", "DW_STAGE", "DW_STAGE_NP2", "DW_FASTV",
          "DW5_DIRECT", "DW_RS1", "DW_RS2", "GEMM_VARIANT", "GEMM_AREG", "GEMM_MA", "GEMM_DEBUG", "SUBSAMPLE_1X1", "GEMM_TR", "TR_DELAY",
-         "TR_CFG", "GEMM_WIDE", "WIDE_NTT", "FC_MFMA", "IMPLICIT_GEMM")
+         "TR_CFG", "GEMM_WIDE", "WIDE_NTT", "FC_MFMA", "IMPLICIT_GEMM", "FUSED_STREAM")
 KNOBS_SET = {}
 
 

@@ -515,6 +515,12 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
 // two m tiles per wave), depthwise activation relu / relu6 / none / leaky, any pointwise activation.
 bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int dw, int out) {
   if (!(kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1)) return false;
+  a->ones = 0x01010101u;
+  a->stream = 0;
+  if (knob("FUSED_STREAM", 1) && fused_stream_supported(*a)) {  // the large planes: fused_dwpw_stream.hip
+    a->stream = 1;
+    return true;
+  }
   if (!(a->h == 14 && a->w == 14 && a->oh == 14 && a->ow == 14 && a->pt == 1 && a->pl == 1)) return false;
   if (a->C % 128 != 0 || a->C < 128 || a->C > 512) return false;
   if (a->pw.M != 256 && a->pw.M != 512) return false;
@@ -593,6 +599,10 @@ static void launch_fused_t(const FusedArgs& a, hipStream_t s) {
 void launch_fused_dwpw(const FusedArgs& a_in, int out, hipStream_t s) {
   FusedArgs a = a_in;
   a.pw.dbg = g_fw_debug;
+  if (a.stream) {
+    launch_fused_stream(a, out, s);
+    return;
+  }
   if (a.pw.M == 512) {
     if (out == OUT_I32) launch_fused_t<2, OUT_I32>(a, s);
     else if (out == OUT_F32) launch_fused_t<2, OUT_F32>(a, s);

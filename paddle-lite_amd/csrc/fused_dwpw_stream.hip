@@ -1,0 +1,308 @@
+// fused_dwpw_stream.hip — depthwise 3x3 stride 1 [int8_out] + pointwise 1x1 in ONE launch for the LARGE planes of the
+// MobileNet programs (112 x 112, 56 x 56, 28 x 28), where the pair is bound by HBM bytes: run as two kernels the int8 tensor
+// between them is written and read back (103 MB of 257 MB for 32 -> 64 @112 at batch 128); here it never leaves the CU.
+// Replaces the instruction pair DepthwiseConv<kInt8,kInt8>::Run (lite/kernels/arm/conv_depthwise.cc:407-446 ->
+// conv3x3s1_depthwise_int8.cc:33-447) ; GemmLikeConv<kInt8,*>::Run (lite/kernels/arm/conv_gemmlike.cc:399-462 ->
+// gemm_prepacked_int8.cc:2582-2744); results bit-identical to the two kernels.
+//
+// The 14 x 14 pairs (fused_dwpw_i8.hip) are latency / issue bound and keep the whole K x tile image of one big block per CU
+// with produce and consume software-pipelined over K rounds.  These pairs are byte bound, their K and M are small, and a
+// plane has thousands of tiles: so the structure is the plain one and the overlap comes from SEVERAL SMALL BLOCKS PER CU in
+// different phases (one block fetching, one on the VALU, one on the matrix pipe):
+//   * tile = TR whole output rows of one image = 224 pixels = 7 MFMA n tiles (TR = 4 / 8 for W = 56 / 28; 448 pixels = 4 rows for W = 112): the output
+//     of a tile is 224 CONTIGUOUS bytes per channel, 16-byte aligned; block = 4 waves, grid = images x tiles;
+//   * produce: lane = (channel, RS-row strip, column quad), quads of a row on consecutive lanes (coalesced 8-byte row windows,
+//     the next iteration's rows fetched under the current one's arithmetic): the strip body of fused_dwpw_i8.hip (in-bounds
+//     windows placed by v_perm_b32, taps on v_dot4_i32_i8, the reference's requantisation) writes each requantised dword into
+//     the activation image in LDS: image[k][288 B]: pixel-linear rows, pitch 288 = 72 dwords = 8 (mod 64) so that the 8 rows x
+//     2 chunks a half-wave's ds_read_b64_tr_b8 touches fall into distinct banks without a swizzle;
+//   * one barrier; consume: a wave owns M / 4 output channels (m tiles) for all 7 n tiles (M = 64: 2 m x 2 n splits), its weight
+//     fragments straight from L2 (each byte of the weights once per block), K-outer; epilogue: requantise, two
+//     v_permlane32_swap give a lane 16 consecutive pixels of one channel = one aligned 16-byte store.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "plhip_device.h"
+#include "plhip_kernels.h"
+#include "dw_common.h"
+#include "gemm_tr_common.h"
+
+namespace plhip {
+
+// TP pixels per tile (224 or 448 = 7 or 14 n tiles); LDS bytes per channel row of the activation image: TP + pad with
+// pitch / 4 = 8 (mod 64): 288 / 544
+constexpr int fs_pitch(int tp) { return tp == 224 ? 288 : 544; }
+
+// W: plane width; K, M: channels in / out; RS: output rows per strip (TR = 224 / W rows per tile, TR % RS == 0); PD: iterations
+// of operands in flight
+template <int W, int K, int M, int TP, int RS, int PD, int OUT, bool DWNN, bool PWNN>
+__global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kernel(FusedArgs a) {
+  constexpr int FS_TP = TP, FS_NT = TP / 32, FS_PITCH = fs_pitch(TP);
+  static_assert((FS_PITCH / 4) % 64 == 8 && FS_PITCH >= TP, "image pitch");
+  constexpr int TR = FS_TP / W, NS = TR / RS, QW = W / 4;   // rows per tile, strips per tile, quads per row
+  constexpr int G = 64 / QW;                                // (channel, strip) groups per wave and iteration
+  constexpr int NGRP = K * NS;                              // groups per tile
+  constexpr int NIT = (NGRP + 4 * G - 1) / (4 * G);         // iterations
+  constexpr int KS = K / 32, MT = M / 32;
+  constexpr int MSPLIT = MT >= 4 ? 4 : MT;                  // waves along M
+  constexpr int NSPLIT = 4 / MSPLIT;                        // waves along the n tiles
+  constexpr int MW = MT / MSPLIT;                           // m tiles per wave
+  constexpr int NW = (FS_NT + NSPLIT - 1) / NSPLIT;         // n tiles per wave (the last split may own fewer)
+  constexpr int NIN = RS + 2;
+  static_assert(FS_TP % W == 0 && TR % RS == 0 && W % 4 == 0 && K % 32 == 0 && M % 32 == 0 && MT % MSPLIT == 0, "geometry");
+  const GemmArgs& g = a.pw;
+  PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.dw_w); PLHIP_PRELOAD(a.dw_scale); PLHIP_PRELOAD(a.dw_bias); PLHIP_PRELOAD(a.dw_act);
+  PLHIP_PRELOAD(a.dw_alpha); PLHIP_PRELOAD(a.n); PLHIP_PRELOAD(a.h); PLHIP_PRELOAD(a.tiles); PLHIP_PRELOAD(a.ones); PLHIP_PRELOAD(g.wp);
+  PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias); PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.NT);
+  extern __shared__ __attribute__((aligned(16))) uint8_t fs_lds[];  // image[K][FS_PITCH]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-contiguous tiles (neighbouring tiles of an image share their halo rows)
+  const unsigned nb = (unsigned)a.tiles, per = (nb + 7) >> 3;
+  const unsigned vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (vb >= nb) return;  // block-uniform
+  const int H = a.h, TPI = g.NT;  // tiles per image (launcher)
+  const int b = (int)(vb / (unsigned)TPI), ti = (int)(vb - (unsigned)b * TPI), tr0 = ti * TR;
+  const int c = lane & 31, h = lane >> 5;
+
+  // ------------------------------------------------------------------ produce
+  const int gl = lane / QW, q = lane - gl * QW;  // group inside the iteration, column quad
+  const bool active = gl < G;
+  // window fetch column and byte selectors (fused_dwpw_i8.hip): the 8 bytes never leave the row
+  const int colq = q == 0 ? 0 : (q == QW - 1 ? W - 8 : 4 * q - 1);
+  const uint32_t sel_lo = q == 0 ? 0x0201000cu : (q == QW - 1 ? 0x06050403u : 0x03020100u);
+  const uint32_t sel_hi = q == 0 ? 0x06050403u : (q == QW - 1 ? 0x0c0c0c07u : 0x07060504u);
+  const float dw_hi2 = a.dw_act == ACT_RELU6 ? fminf(a.dw_alpha + a.dw_alpha, 254.f) : 254.f;
+  const float dw_leak = a.dw_act == ACT_LEAKY ? a.dw_alpha : 1.f;
+  const uint32_t plane = (uint32_t)H * W;
+
+  // PD iterations of operands in flight (a ring of PD register sets): an iteration is ~100-150 VALU, a fetch from HBM under
+  // load ~2 us: with one iteration ahead every wave waited for its rows (first form: 61 / 45 / 33 us for the three pairs)
+  uint32_t in[PD][NIN][2];  // row windows
+  uint32_t wraw[PD][3];     // filter bytes as fetched (masked / doubled in compute: nothing in fetch waits for a load)
+  float scraw[PD], biraw[PD];
+  auto task = [&](int it, int& ch, int& strip, int& r0) {
+    int gi = (it * 4 + wave) * G + (active ? gl : 0);
+    if (gi >= NGRP) gi = NGRP - 1;  // surplus groups of the last iteration recompute the last one (same values, same place)
+    ch = gi / NS;
+    strip = gi - ch * NS;
+    r0 = tr0 + strip * RS;          // first output row of the strip
+    if (r0 > H - RS) r0 = H - RS;   // rows past the image (the last tile of a 28-row plane): any valid strip, never stored
+  };
+  using std::integral_constant;
+  auto fetch = [&](auto it_c) __attribute__((always_inline)) {
+    constexpr int it = decltype(it_c)::value, s = it % PD;
+    int ch, strip, r0;
+    task(it, ch, strip, r0);
+    const uint32_t off0 = (uint32_t)(b * K + ch) * plane + (uint32_t)r0 * W + colq;  // input row r0
+    const bool top = r0 == 0, bot = r0 + RS == H;
+    const uint8_t* xs = reinterpret_cast<const uint8_t*>(a.x);
+    __builtin_memcpy(in[s][0], xs + (top ? off0 : off0 - W), 8);
+#pragma unroll
+    for (int t = 1; t <= RS; ++t) __builtin_memcpy(in[s][t], xs + off0 + (t - 1) * W, 8);
+    __builtin_memcpy(in[s][RS + 1], xs + (bot ? off0 + (RS - 1) * W : off0 + RS * W), 8);
+    const int8_t* wp = a.dw_w + (size_t)ch * 9;
+    __builtin_memcpy(&wraw[s][0], wp, 4);
+    __builtin_memcpy(&wraw[s][1], wp + 3, 4);
+    __builtin_memcpy(&wraw[s][2], wp + 5, 4);
+    scraw[s] = a.dw_scale[ch];
+    biraw[s] = (a.dw_bias ? a.dw_bias : a.dw_scale)[ch];
+  };
+  auto compute = [&](auto it_c) __attribute__((always_inline)) {
+    constexpr int it = decltype(it_c)::value, s = it % PD;
+    int ch, strip, r0;
+    task(it, ch, strip, r0);
+    const uint32_t zt = r0 == 0 ? 0u : 0xffffffffu, zb = r0 + RS == H ? 0u : 0xffffffffu;  // the strip's first / last input row outside the image
+    const uint32_t ldsw = (uint32_t)ch * FS_PITCH + (uint32_t)(strip * RS) * W + 4 * q;   // image address of (channel, strip row 0, quad)
+    int dacc[RS][4];
+    const uint32_t wr[3] = {wraw[s][0] & 0xffffffu, wraw[s][1] & 0xffffffu, wraw[s][2] >> 8};  // packed filter rows (w0, w1, w2, 0)
+    const uint32_t w0t = wr[0] & zt, w2b = wr[2] & zb;
+    const float dsc = scraw[s] + scraw[s], dbi = a.dw_bias ? biraw[s] + biraw[s] : 0.f;
+#pragma unroll
+    for (int t = 0; t < NIN; ++t) {
+      const uint32_t e0 = __builtin_amdgcn_perm(in[s][t][1], in[s][t][0], sel_lo), e1 = __builtin_amdgcn_perm(in[s][t][1], in[s][t][0], sel_hi);
+      uint32_t win[4];
+      win[0] = e0;
+      win[1] = __builtin_amdgcn_alignbyte(e1, e0, 1);
+      win[2] = __builtin_amdgcn_alignbyte(e1, e0, 2);
+      win[3] = __builtin_amdgcn_alignbyte(e1, e0, 3);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int o = t - r;
+        if (o < 0 || o >= RS) continue;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          dacc[o][jj] = r == 0 ? sdot4_first(win[jj], t == 0 ? w0t : wr[0])
+                               : __builtin_amdgcn_sdot4((int)win[jj], (int)(t == NIN - 1 ? w2b : wr[r]), dacc[o][jj], false);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < RS; ++o) {
+      const uint32_t pk = DWNN ? requant4_nn_rtz(dacc[o], dsc, dbi, dw_hi2, a.ones)
+                               : dw_requant4<ACT_LEAKY>(dacc[o], dsc, dbi, dw_leak, -254.f, 254.f);
+      if (active) *reinterpret_cast<uint32_t*>(fs_lds + ldsw + o * W) = pk;
+    }
+  };
+  auto prime = [&](auto self, auto it_c) __attribute__((always_inline)) -> void {
+    constexpr int it = decltype(it_c)::value;
+    if constexpr (it < PD && it < NIT) {
+      fetch(it_c);
+      self(self, integral_constant<int, it + 1>{});
+    }
+  };
+  prime(prime, integral_constant<int, 0>{});
+  auto steps = [&](auto self, auto it_c) __attribute__((always_inline)) -> void {
+    constexpr int it = decltype(it_c)::value;
+    if constexpr (it < NIT) {
+      compute(it_c);
+      if constexpr (it + PD < NIT) fetch(integral_constant<int, it + PD>{});
+      self(self, integral_constant<int, it + 1>{});
+    }
+  };
+  steps(steps, integral_constant<int, 0>{});
+  __syncthreads();
+
+  // ------------------------------------------------------------------ consume
+  // wave -> (m split, n split): m tiles [ms MW, ms MW + MW), n tiles [ns NW, min(7, ns NW + NW))
+  const int ms = wave % MSPLIT, ns = wave / MSPLIT;
+  const int mt0 = ms * MW, n0 = ns * NW;
+  const int nmine = n0 + NW <= FS_NT ? NW : FS_NT - n0;  // wave-uniform
+  // transposed read: lane 2 q' + p of a 16-lane group -> row q' (k % 8), sub-chunk p; 16-lane group parity -> 16-pixel chunk
+  // parity; k half h -> kg {2h, 2h + 1}
+  const uint32_t trb = (uint32_t)(((h * 2) * 8 + ((lane & 15) >> 1)) * FS_PITCH + ((lane >> 4) & 1) * 16 + (lane & 1) * 8 + n0 * 32);
+  const uint8_t* const wpk = reinterpret_cast<const uint8_t*>(g.wp) + (size_t)mt0 * KS * 1024;  // [mt][ks][64 lanes][16 B]
+  const uint32_t wlane = (uint32_t)lane * 16;
+  v16i acc[NW][MW];
+#pragma unroll
+  for (int n = 0; n < NW; ++n)
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][m][r] = 0;
+  v4i Wf[2][MW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m) Wf[0][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS) * 1024 + wlane);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int m = 0; m < MW; ++m) Wf[(ks + 1) & 1][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS + ks + 1) * 1024 + wlane);
+    }
+    const uint32_t ka = trb + (uint32_t)ks * (32 * FS_PITCH);
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      if (n < nmine) {
+        const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i_ptr_t)(fs_lds + ka + n * 32));
+        const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i_ptr_t)(fs_lds + ka + n * 32 + 8 * FS_PITCH));
+        const v4i av = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+        for (int m = 0; m < MW; ++m) acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, Wf[ks & 1][m], acc[n][m], 0, 0, 0);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // accumulator register r of n tile n: pixel 32 (n0 + n) + 8 (r >> 2) + 4 h + (r & 3); lane (c, h) owns channel 32 (mt0 + m) + c
+  const int vpx = (H - tr0 < TR ? H - tr0 : TR) * W;  // valid pixels of this tile (a multiple of 16)
+  const float hi2 = g.act == ACT_RELU6 ? fminf(g.alpha + g.alpha, 254.f) : 254.f;
+  const float leak = g.act == ACT_LEAKY ? g.alpha : 1.f;
+  const float fcap = g.act == ACT_RELU6 ? g.alpha : __builtin_huge_valf();
+  const float flo = (g.act == ACT_RELU || g.act == ACT_RELU6) ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+  for (int m = 0; m < MW; ++m) {
+    const int mch = (mt0 + m) * 32 + c;
+    float sc = 1.f, bi = 0.f;
+    if (OUT != OUT_I32) {
+      sc = g.scale[mch];
+      if (g.bias) bi = g.bias[mch];
+    }
+    const size_t obase = ((size_t)b * M + mch) * plane + (size_t)tr0 * W;
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      if (n >= nmine) continue;
+      const int px0 = (n0 + n) * 32;
+      if (OUT == OUT_I8) {
+        const float s2 = sc + sc, b2 = bi + bi;
+        uint32_t edw[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          int v[4] = {acc[n][m][4 * gq], acc[n][m][4 * gq + 1], acc[n][m][4 * gq + 2], acc[n][m][4 * gq + 3]};
+          edw[gq] = PWNN ? requant4_nn_rtz(v, s2, b2, hi2, a.ones) : dw_requant4<ACT_LEAKY>(v, s2, b2, leak, -254.f, 254.f);
+        }
+        // half exchange: every lane gets 16 consecutive pixels of its channel (h = 0: px0 + 0..15, h = 1: px0 + 16..31)
+        auto s02 = __builtin_amdgcn_permlane32_swap(edw[0], edw[2], false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(edw[1], edw[3], false, false);
+        const v4i v = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+        const int px = px0 + 16 * h;
+        if (px < vpx) *reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(g.y) + obase + px) = v;  // 16-byte aligned
+      } else {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int px = px0 + 8 * gq + 4 * h;
+          if (px >= vpx) continue;
+          if (OUT == OUT_F32) {
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float y = __fmaf_rn((float)acc[n][m][4 * gq + e], sc, bi);
+              if (g.act == ACT_LEAKY) y = y > 0.f ? y : g.alpha * y;
+              f[e] = fminf(fmaxf(y, flo), fcap);
+            }
+            const v4f v = {f[0], f[1], f[2], f[3]};
+            *reinterpret_cast<v4f*>(reinterpret_cast<float*>(g.y) + obase + px) = v;
+          } else {
+            const v4i v = {acc[n][m][4 * gq], acc[n][m][4 * gq + 1], acc[n][m][4 * gq + 2], acc[n][m][4 * gq + 3]};
+            *reinterpret_cast<v4i*>(reinterpret_cast<int*>(g.y) + obase + px) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// shapes of the streaming kernel: (W, K, M) = (112, 32, 64), (56, 128, 128), (28, 256, 256): MobileNetV1's stride-1 pairs on
+// the large planes; 3x3, stride 1, dilation 1, pad 1, square planes
+bool fused_stream_supported(const FusedArgs& a) {
+  if (!(a.h == a.w && a.oh == a.h && a.ow == a.w && a.pt == 1 && a.pl == 1 && a.stride == 1)) return false;
+  if (a.n < 1 || (long)a.n * a.C * a.h * a.w >= ((long)1 << 31) - 65536 || (long)a.n * a.pw.M * a.h * a.w >= ((long)1 << 31)) return false;
+  return (a.w == 112 && a.C == 32 && a.pw.M == 64) || (a.w == 56 && a.C == 128 && a.pw.M == 128) || (a.w == 28 && a.C == 256 && a.pw.M == 256);
+}
+
+template <int W, int K, int M, int TP, int RS, int PD, int OUT>
+static void launch_stream_t(FusedArgs a, hipStream_t s) {
+  constexpr int TR = TP / W;
+  a.pw.NT = (a.h + TR - 1) / TR;  // tiles per image
+  a.tiles = a.n * a.pw.NT;
+  const unsigned blocks = (unsigned)((a.tiles + 7) / 8 * 8);
+  const size_t lds = (size_t)K * fs_pitch(TP);
+  const bool dwnn = a.dw_act == ACT_RELU || a.dw_act == ACT_RELU6;
+  const bool pwnn = OUT == OUT_I8 && (a.pw.act == ACT_RELU || a.pw.act == ACT_RELU6);
+#define PLHIP_FS_LAUNCH(DN, PN)                                                                                  \
+  do {                                                                                                           \
+    auto kfn = fused_dwpw_stream_kernel<W, K, M, TP, RS, PD, OUT, DN, PN>;                                               \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, s, a);                                                 \
+  } while (0)
+  if (dwnn && pwnn) PLHIP_FS_LAUNCH(true, true);
+  else if (dwnn) PLHIP_FS_LAUNCH(true, false);
+  else if (pwnn) PLHIP_FS_LAUNCH(false, true);
+  else PLHIP_FS_LAUNCH(false, false);
+#undef PLHIP_FS_LAUNCH
+}
+
+template <int W, int K, int M, int TP, int RS, int PD>
+static void launch_stream_o(const FusedArgs& a, int out, hipStream_t s) {
+  if (out == OUT_I32) launch_stream_t<W, K, M, TP, RS, PD, OUT_I32>(a, s);
+  else if (out == OUT_F32) launch_stream_t<W, K, M, TP, RS, PD, OUT_F32>(a, s);
+  else launch_stream_t<W, K, M, TP, RS, PD, OUT_I8>(a, s);
+}
+
+void launch_fused_stream(const FusedArgs& a, int out, hipStream_t s) {
+  // 112-wide: 4-row tiles of 448 pixels (2-row tiles fetched and cut every input row twice: 61 us, the two kernels 56)
+  if (a.w == 112) launch_stream_o<112, 32, 64, 448, 4, 4>(a, out, s);
+  else if (a.w == 56) launch_stream_o<56, 128, 128, 224, 4, 4>(a, out, s);
+  else launch_stream_o<28, 256, 256, 224, 4, 4>(a, out, s);
+}
+
+}  // namespace plhip

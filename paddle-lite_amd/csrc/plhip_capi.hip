@@ -911,7 +911,7 @@ Knob g_knobs[] = {
     {"STEM7", 0, false}, {"DW_STAGE", 0, false}, {"DW_STAGE_NP2", 0, false}, {"DW_FASTV", 0, false}, {"DW5_DIRECT", 0, false},
     {"DW_RS1", 0, false}, {"DW_RS2", 0, false}, {"GEMM_VARIANT", 0, false}, {"GEMM_AREG", 0, false}, {"GEMM_MA", 0, false},
     {"GEMM_DEBUG", 0, false}, {"SUBSAMPLE_1X1", 0, false}, {"GEMM_TR", 0, false}, {"TR_DELAY", 0, false}, {"TR_CFG", 0, false},
-    {"GEMM_WIDE", 0, false}, {"WIDE_NTT", 0, false}, {"FC_MFMA", 0, false}, {"IMPLICIT_GEMM", 0, false}};
+    {"GEMM_WIDE", 0, false}, {"WIDE_NTT", 0, false}, {"FC_MFMA", 0, false}, {"IMPLICIT_GEMM", 0, false}, {"FUSED_STREAM", 0, false}};
 }  // namespace
 int knob(const char* name, int dflt) {
   for (const Knob& k : g_knobs)

@@ -163,11 +163,14 @@ struct FusedArgs {
   int n, C, h, w, oh, ow, pt, pl, stride;
   int tiles;              // launch plan (fused_dwpw_plan): (image, half-plane) tiles = 2 n
   unsigned ones;          // 0x01010101 as a scalar operand (the byte-wise +1 of the packed rounding)
+  int stream;             // 1 = the streaming kernel of the large planes (fused_dwpw_stream.hip), 0 = the 14 x 14 kernel
   GemmArgs pw;            // wp, y, scale, bias, M, KS, HWY (= oh*ow), y_bstride, act, alpha
 };
 // fills the plan from (n, C, h, w, oh, ow, pt, pl, stride, pw.M); false = shape outside the fused path
 bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int dw, int out);
 void launch_fused_dwpw(const FusedArgs& a, int out, hipStream_t s);
+bool fused_stream_supported(const FusedArgs& a);   // fused_dwpw_stream.hip: the 112 / 56 / 28-wide stride-1 pairs
+void launch_fused_stream(const FusedArgs& a, int out, hipStream_t s);
 void debug_set_fused(int v);                        // bit 5 (32): timeline stamps
 int debug_read_fw_stamps(void* dst, size_t bytes);
 

@@ -51,9 +51,17 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         (2, 256, 14, 14, 1, (1, 1, 1, 1), 256, 1, 0, False),    # fp32 output
         (1, 128, 14, 14, 1, (1, 1, 1, 1), 512, 4, 1, True),     # leaky depthwise
         (9, 512, 14, 14, 1, (1, 1, 1, 1), 512, 1, 2, True),     # 18 tiles: ragged XCD shares
+        # the streaming kernel of the large planes (fused_dwpw_stream.hip)
+        (2, 32, 112, 112, 1, (1, 1, 1, 1), 64, 1, 1, True),     # dw2 / pw2: 2-row tiles, 2 m x 2 n wave splits
+        (3, 128, 56, 56, 1, (1, 1, 1, 1), 128, 2, 2, True),     # dw4 / pw4, relu6 both: 4-row tiles, a wave = one m tile x 7 n tiles
+        (2, 256, 28, 28, 1, (1, 1, 1, 1), 256, 1, 1, True),     # dw6 / pw6: 8-row tiles, the last tile of an image half empty
+        (1, 128, 56, 56, 1, (1, 1, 1, 1), 128, 0, 4, False),    # no depthwise activation, leaky pointwise, fp32 output
+        (1, 32, 112, 112, 1, (1, 1, 1, 1), 64, 4, 0, True),     # leaky depthwise, no pointwise activation
         # outside the fused path (the predictor runs the two kernels): reported as unsupported
         (2, 32, 16, 16, 1, (1, 1, 1, 1), 64, 1, 1, True),
         (2, 64, 16, 16, 2, (1, 1, 1, 1), 128, 1, 1, True),
+        (2, 64, 112, 112, 2, (1, 1, 1, 1), 128, 1, 1, True),    # stride 2 on a large plane
+        (2, 64, 56, 56, 1, (1, 1, 1, 1), 128, 1, 1, True),      # a large plane with another channel count
         (2, 96, 7, 7, 1, (1, 1, 1, 1), 160, 1, 1, False),
         (1, 40, 9, 13, 2, (0, 1, 1, 0), 33, 0, 4, True),
         (5, 256, 28, 28, 2, (1, 1, 1, 1), 512, 2, 2, True),
@@ -67,7 +75,7 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         ran.append(_case(gpu_ctx, capi, plref, rng, n, c, h, w, st, pad, m, da, pa, i8, pw_alpha=(6.0 if pa == 2 else 0.3),
                          dw_alpha=(6.0 if da == 2 else (0.2 if da == 4 else 0.0))))
     print("fused cases run:", ran)
-    assert ran[:7] == [True] * 7 and not any(ran[7:]), ran
+    assert ran[:12] == [True] * 12 and not any(ran[12:]), ran
 
 
 def test_fused_unsupported_shapes_are_reported(gpu_ctx, pkg):

@@ -43,6 +43,16 @@ fi
 if [ "$PART" = "1" ]; then exit 0; fi
 cd $R
 timeout -k 10 200 python tools/opbench.py all 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench.txt || exit 1
+# round 4: the fused depthwise -> pointwise kernel: the 13 pairs (fused where the kernel takes them, else the two kernels), its
+# in-kernel timeline at batch 128 / 256 and in its timing experiments, the probes behind its design
+timeout -k 10 200 python tools/opbench.py fused 2>&1 | cut -c1-110 | grep "fused\|2-krn" > $O/opbench_fused.txt || exit 1
+timeout -k 10 100 python tools/fused_timeline.py > $O/fused_timeline_b128.txt 2>&1 || exit 1
+timeout -k 10 100 python tools/fused_timeline.py --batch 256 > $O/fused_timeline_b256.txt 2>&1 || exit 1
+for e in 1 2 3 19 4; do timeout -k 10 100 python tools/fused_timeline.py --exp $e > $O/fused_timeline_exp$e.txt 2>&1 || exit 1; done
+[ -x tools/_probe_coexec ] && ./tools/_probe_coexec > $O/probe_coexec.txt 2>&1
+[ -x tools/_probe_rtz ] && ./tools/_probe_rtz > $O/probe_cvt_rtz.txt 2>&1
+PLHIP_BENCH_FUSE_DWPW=0 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_dwpw_off.json 2>/dev/null || exit 1
+PLHIP_BENCH_FUSE_DWPW=0 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_dwpw_off_inflight1.json 2>/dev/null || exit 1
 timeout -k 10 200 python tools/opbench.py all --batch 256 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench_b256.txt || exit 1
 PLHIP_GEMM_WIDE=0 timeout -k 10 200 python tools/opbench.py pw 2>&1 | cut -c1-110 > $O/opbench_pw_wide_off.txt || exit 1
 for l in pw8 pw6 pw13; do PLHIP_GEMM_DEBUG=32 timeout -k 10 100 python tools/wide_timeline.py $l > $O/wide_timeline_$l.txt 2>&1 || exit 1; done

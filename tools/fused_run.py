@@ -17,22 +17,25 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--exp", type=int, default=0)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--c", type=int, default=512)
+ap.add_argument("--m", type=int, default=512)
+ap.add_argument("--hw", type=int, default=14)
 args = ap.parse_args()
-B, c, m = args.batch, 512, 512
+B, c, m, hw = args.batch, args.c, args.m, args.hw
 rng = np.random.default_rng(0)
 with capi.Context(0) as ctx:
     L = ctx.L
     L.plhip_debug_set.argtypes = [C.c_char_p, C.c_int]
-    d = capi.conv_desc(B, c, 14, 14, c, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), c, capi.ACT_RELU, 0.0)
-    dp = capi.conv_desc(B, c, 14, 14, m, 1, 1, act=capi.ACT_RELU)
-    dx = ctx.to_device(rng.integers(-127, 128, (B, c, 14, 14), dtype=np.int8))
+    d = capi.conv_desc(B, c, hw, hw, c, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), c, capi.ACT_RELU, 0.0)
+    dp = capi.conv_desc(B, c, hw, hw, m, 1, 1, act=capi.ACT_RELU)
+    dx = ctx.to_device(rng.integers(-127, 128, (B, c, hw, hw), dtype=np.int8))
     dwd = ctx.to_device(rng.integers(-127, 128, (c, 1, 3, 3), dtype=np.int8))
     dsd = ctx.to_device(np.full(c, 1e-2, np.float32))
     dwr = ctx.to_device(rng.integers(-127, 128, (m, c, 1, 1), dtype=np.int8))
     dwp = ctx.malloc(L.plhip_conv_packed_weight_bytes(C.byref(dp)))
     ctx.check(L.plhip_pack_conv_weights(ctx.h, C.byref(dp), dwr, dwp), "pack")
     dsp = ctx.to_device(np.full(m, 1e-4, np.float32))
-    dy = ctx.malloc(B * m * 196)
+    dy = ctx.malloc(B * m * hw * hw)
     if args.exp:
         assert L.plhip_debug_set(b"fused_exp", args.exp) == 0
     for _ in range(args.reps):

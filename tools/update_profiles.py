@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = os.path.join(ROOT, "gpurun_out", "evidence")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def cp(src, dst):
@@ -32,7 +32,10 @@ for f in ("bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.j
           "wide_timeline_pw14.txt", "gemm_timeline_pw8_ring.txt", "c2bench.txt", "pmc_sq_c3.csv", "pmc_sq_c4.csv",
           "bench_driver_form.json", "opbench_resnet50_3x3.txt", "opbench_resnet50_3x3_patch_off.txt", "opbench_resnet50_3x3_no_epilogue.txt",
           "opbench_dw5x5.txt", "opbench_dw5x5_lds_band.txt", "opbench_resnet50_3x3_s2_patch_off.txt", "patch_timeline_res3a_s2.txt",
-          "patch_timeline_res5a_s2.txt", "patch_timeline_c2.txt", "patch_timeline_res2.txt", "patch_timeline_res4.txt"):
+          "patch_timeline_res5a_s2.txt", "patch_timeline_c2.txt", "patch_timeline_res2.txt", "patch_timeline_res4.txt",
+          "opbench_fused.txt", "fused_timeline_b128.txt", "fused_timeline_b256.txt", "fused_timeline_exp1.txt", "fused_timeline_exp2.txt",
+          "fused_timeline_exp3.txt", "fused_timeline_exp19.txt", "fused_timeline_exp4.txt", "probe_coexec.txt", "probe_cvt_rtz.txt",
+          "bench_dwpw_off.json", "bench_dwpw_off_inflight1.json"):
     if os.path.exists(os.path.join(E, f)):
         cp(f, f)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
