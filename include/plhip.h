@@ -213,6 +213,7 @@ plhip_status plhip_selftest(plhip_ctx* ctx);
  * [tile][wave][16] shader-clock stamps).  Returns 0, or -1 for an unknown key. ---- */
 int plhip_debug_set(const char* key, int value);
 int plhip_debug_read_fw_stamps(void* dst_host, size_t bytes);
+int plhip_debug_read_fs_stamps(void* dst_host, size_t bytes); /* the streaming fused kernel: [tile < 2048][wave 4][8] */
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ EXPORTS = [
     "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
     "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
     "plhip_pool2d_f32", "plhip_pool2d_max_i8", "plhip_elementwise_add_f32", "plhip_selftest",
-    "plhip_debug_set", "plhip_debug_read_fw_stamps",
+    "plhip_debug_set", "plhip_debug_read_fw_stamps", "plhip_debug_read_fs_stamps",
 ]
 
 

@@ -34,6 +34,20 @@ namespace plhip {
 // pitch / 4 = 8 (mod 64): 288 / 544
 constexpr int fs_pitch(int tp) { return tp == 224 ? 288 : 544; }
 
+// diagnostic timeline (plhip_debug_set("fused_stamps", 1)): per wave of the first 2048 tiles: 0 realtime, 1 entry, 2 operands of
+// the first PD iterations requested, 3 produced, 4 behind the barrier, 5 multiplied, 6 stores issued, 7 realtime end
+constexpr int FS_STAMP_SLOTS = 8;
+__device__ unsigned long long g_fs_stamps[2048 * 4 * FS_STAMP_SLOTS];
+int debug_read_fs_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(g_fs_stamps)) bytes = sizeof(g_fs_stamps);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fs_stamps), bytes) == hipSuccess ? 0 : -1;
+}
+#define PLHIP_FS_STAMP(i)                                                                                                  \
+  do {                                                                                                                     \
+    if (diag && lane == 0) g_fs_stamps[((size_t)vb * 4 + wave) * FS_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memtime();    \
+  } while (0)
+
 // W: plane width; K, M: channels in / out; RS: output rows per strip (TR = 224 / W rows per tile, TR % RS == 0); PD: iterations
 // of operands in flight
 template <int W, int K, int M, int TP, int RS, int PD, int OUT, bool DWNN, bool PWNN>
@@ -55,7 +69,7 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
   PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.dw_w); PLHIP_PRELOAD(a.dw_scale); PLHIP_PRELOAD(a.dw_bias); PLHIP_PRELOAD(a.dw_act);
   PLHIP_PRELOAD(a.dw_alpha); PLHIP_PRELOAD(a.n); PLHIP_PRELOAD(a.h); PLHIP_PRELOAD(a.tiles); PLHIP_PRELOAD(a.ones); PLHIP_PRELOAD(g.wp);
   PLHIP_PRELOAD(g.y); PLHIP_PRELOAD(g.scale); PLHIP_PRELOAD(g.bias); PLHIP_PRELOAD(g.act); PLHIP_PRELOAD(g.alpha); PLHIP_PRELOAD(g.NT);
-  extern __shared__ __attribute__((aligned(16))) uint8_t fs_lds[];  // image[K][FS_PITCH]
+  extern __shared__ __attribute__((aligned(16))) uint8_t fs_lds[];  // image[K][FS_PITCH], then the depthwise parameters [K][32 B]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-contiguous tiles (neighbouring tiles of an image share their halo rows)
@@ -65,6 +79,9 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
   const int H = a.h, TPI = g.NT;  // tiles per image (launcher)
   const int b = (int)(vb / (unsigned)TPI), ti = (int)(vb - (unsigned)b * TPI), tr0 = ti * TR;
   const int c = lane & 31, h = lane >> 5;
+  const bool diag = (g.dbg & 32) != 0 && vb < 2048;
+  if (diag && lane == 0) g_fs_stamps[((size_t)vb * 4 + wave) * FS_STAMP_SLOTS] = __builtin_amdgcn_s_memrealtime();
+  PLHIP_FS_STAMP(1);
 
   // ------------------------------------------------------------------ produce
   const int gl = lane / QW, q = lane - gl * QW;  // group inside the iteration, column quad
@@ -80,8 +97,21 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
   // PD iterations of operands in flight (a ring of PD register sets): an iteration is ~100-150 VALU, a fetch from HBM under
   // load ~2 us: with one iteration ahead every wave waited for its rows (first form: 61 / 45 / 33 us for the three pairs)
   uint32_t in[PD][NIN][2];  // row windows
-  uint32_t wraw[PD][3];     // filter bytes as fetched (masked / doubled in compute: nothing in fetch waits for a load)
-  float scraw[PD], biraw[PD];
+  // depthwise parameters of all K channels, once per block, into LDS: (w0 w1 w2 0 | w3 w4 w5 0 | w6 w7 w8 0 | 2 scale | 2 bias):
+  // per iteration a lane then reads ONE 16-byte and one 4-byte LDS word instead of five global loads (the vector-memory
+  // instructions were the startup cost of a block: 44 per wave, 6.7 k cycles to issue with four blocks per CU)
+  uint8_t* const prm = fs_lds + (size_t)K * FS_PITCH;
+  static_assert(K <= 256, "one channel's parameters per thread");
+  uint32_t pw0 = 0, pw1 = 0, pw2 = 0;
+  float psc0 = 0.f, pbi0 = 0.f;
+  if ((int)threadIdx.x < K) {  // requested first; stored behind the row fetches below (nothing in front of them waits)
+    const int8_t* wp = a.dw_w + (size_t)threadIdx.x * 9;
+    __builtin_memcpy(&pw0, wp, 4);
+    __builtin_memcpy(&pw1, wp + 3, 4);
+    __builtin_memcpy(&pw2, wp + 5, 4);
+    psc0 = a.dw_scale[threadIdx.x];
+    pbi0 = (a.dw_bias ? a.dw_bias : a.dw_scale)[threadIdx.x];
+  }
   auto task = [&](int it, int& ch, int& strip, int& r0) {
     int gi = (it * 4 + wave) * G + (active ? gl : 0);
     if (gi >= NGRP) gi = NGRP - 1;  // surplus groups of the last iteration recompute the last one (same values, same place)
@@ -102,12 +132,6 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
 #pragma unroll
     for (int t = 1; t <= RS; ++t) __builtin_memcpy(in[s][t], xs + off0 + (t - 1) * W, 8);
     __builtin_memcpy(in[s][RS + 1], xs + (bot ? off0 + (RS - 1) * W : off0 + RS * W), 8);
-    const int8_t* wp = a.dw_w + (size_t)ch * 9;
-    __builtin_memcpy(&wraw[s][0], wp, 4);
-    __builtin_memcpy(&wraw[s][1], wp + 3, 4);
-    __builtin_memcpy(&wraw[s][2], wp + 5, 4);
-    scraw[s] = a.dw_scale[ch];
-    biraw[s] = (a.dw_bias ? a.dw_bias : a.dw_scale)[ch];
   };
   auto compute = [&](auto it_c) __attribute__((always_inline)) {
     constexpr int it = decltype(it_c)::value, s = it % PD;
@@ -116,9 +140,10 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
     const uint32_t zt = r0 == 0 ? 0u : 0xffffffffu, zb = r0 + RS == H ? 0u : 0xffffffffu;  // the strip's first / last input row outside the image
     const uint32_t ldsw = (uint32_t)ch * FS_PITCH + (uint32_t)(strip * RS) * W + 4 * q;   // image address of (channel, strip row 0, quad)
     int dacc[RS][4];
-    const uint32_t wr[3] = {wraw[s][0] & 0xffffffu, wraw[s][1] & 0xffffffu, wraw[s][2] >> 8};  // packed filter rows (w0, w1, w2, 0)
+    const v4i pv = *reinterpret_cast<const v4i*>(prm + ch * 32);
+    const uint32_t wr[3] = {(uint32_t)pv[0], (uint32_t)pv[1], (uint32_t)pv[2]};  // packed filter rows (w0, w1, w2, 0)
     const uint32_t w0t = wr[0] & zt, w2b = wr[2] & zb;
-    const float dsc = scraw[s] + scraw[s], dbi = a.dw_bias ? biraw[s] + biraw[s] : 0.f;
+    const float dsc = __uint_as_float((uint32_t)pv[3]), dbi = __uint_as_float(*reinterpret_cast<const uint32_t*>(prm + ch * 32 + 16));
 #pragma unroll
     for (int t = 0; t < NIN; ++t) {
       const uint32_t e0 = __builtin_amdgcn_perm(in[s][t][1], in[s][t][0], sel_lo), e1 = __builtin_amdgcn_perm(in[s][t][1], in[s][t][0], sel_hi);
@@ -152,18 +177,8 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
     }
   };
   prime(prime, integral_constant<int, 0>{});
-  auto steps = [&](auto self, auto it_c) __attribute__((always_inline)) -> void {
-    constexpr int it = decltype(it_c)::value;
-    if constexpr (it < NIT) {
-      compute(it_c);
-      if constexpr (it + PD < NIT) fetch(integral_constant<int, it + PD>{});
-      self(self, integral_constant<int, it + 1>{});
-    }
-  };
-  steps(steps, integral_constant<int, 0>{});
-  __syncthreads();
-
-  // ------------------------------------------------------------------ consume
+  PLHIP_FS_STAMP(2);
+  // ---- the consumer's first operands, requested here so that they arrive under the depthwise arithmetic
   // wave -> (m split, n split): m tiles [ms MW, ms MW + MW), n tiles [ns NW, min(7, ns NW + NW))
   const int ms = wave % MSPLIT, ns = wave / MSPLIT;
   const int mt0 = ms * MW, n0 = ns * NW;
@@ -173,6 +188,41 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
   const uint32_t trb = (uint32_t)(((h * 2) * 8 + ((lane & 15) >> 1)) * FS_PITCH + ((lane >> 4) & 1) * 16 + (lane & 1) * 8 + n0 * 32);
   const uint8_t* const wpk = reinterpret_cast<const uint8_t*>(g.wp) + (size_t)mt0 * KS * 1024;  // [mt][ks][64 lanes][16 B]
   const uint32_t wlane = (uint32_t)lane * 16;
+  v4i Wf[2][MW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m) Wf[0][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS) * 1024 + wlane);
+  float psc[MW], pbi[MW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m) {
+    psc[m] = 1.f;
+    pbi[m] = 0.f;
+    if (OUT != OUT_I32) {
+      psc[m] = g.scale[(mt0 + m) * 32 + c];
+      pbi[m] = (g.bias ? g.bias : g.scale)[(mt0 + m) * 32 + c];
+      if (!g.bias) pbi[m] = 0.f;
+    }
+  }
+  if ((int)threadIdx.x < K) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(prm + threadIdx.x * 32);
+    const v4i pv = {(int)(pw0 & 0xffffffu), (int)(pw1 & 0xffffffu), (int)(pw2 >> 8), (int)__float_as_uint(psc0 + psc0)};
+    *reinterpret_cast<v4i*>(o) = pv;
+    o[4] = a.dw_bias ? __float_as_uint(pbi0 + pbi0) : 0u;
+  }
+  __syncthreads();  // the parameters are in LDS (the row fetches above are in flight meanwhile)
+  auto steps = [&](auto self, auto it_c) __attribute__((always_inline)) -> void {
+    constexpr int it = decltype(it_c)::value;
+    if constexpr (it < NIT) {
+      compute(it_c);
+      if constexpr (it + PD < NIT) fetch(integral_constant<int, it + PD>{});
+      self(self, integral_constant<int, it + 1>{});
+    }
+  };
+  steps(steps, integral_constant<int, 0>{});
+  PLHIP_FS_STAMP(3);
+  __syncthreads();
+  PLHIP_FS_STAMP(4);
+
+  // ------------------------------------------------------------------ consume
   v16i acc[NW][MW];
 #pragma unroll
   for (int n = 0; n < NW; ++n)
@@ -180,9 +230,6 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
     for (int m = 0; m < MW; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][m][r] = 0;
-  v4i Wf[2][MW];
-#pragma unroll
-  for (int m = 0; m < MW; ++m) Wf[0][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS) * 1024 + wlane);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) {
@@ -202,6 +249,7 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
     }
   }
 
+  PLHIP_FS_STAMP(5);
   // ------------------------------------------------------------------ epilogue
   // accumulator register r of n tile n: pixel 32 (n0 + n) + 8 (r >> 2) + 4 h + (r & 3); lane (c, h) owns channel 32 (mt0 + m) + c
   const int vpx = (H - tr0 < TR ? H - tr0 : TR) * W;  // valid pixels of this tile (a multiple of 16)
@@ -212,11 +260,7 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
     const int mch = (mt0 + m) * 32 + c;
-    float sc = 1.f, bi = 0.f;
-    if (OUT != OUT_I32) {
-      sc = g.scale[mch];
-      if (g.bias) bi = g.bias[mch];
-    }
+    const float sc = psc[m], bi = pbi[m];
     const size_t obase = ((size_t)b * M + mch) * plane + (size_t)tr0 * W;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
@@ -259,6 +303,8 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
       }
     }
   }
+  PLHIP_FS_STAMP(6);
+  if (diag && lane == 0) g_fs_stamps[((size_t)vb * 4 + wave) * FS_STAMP_SLOTS + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
 // shapes of the streaming kernel: (W, K, M) = (112, 32, 64), (56, 128, 128), (28, 256, 256): MobileNetV1's stride-1 pairs on
@@ -275,7 +321,7 @@ static void launch_stream_t(FusedArgs a, hipStream_t s) {
   a.pw.NT = (a.h + TR - 1) / TR;  // tiles per image
   a.tiles = a.n * a.pw.NT;
   const unsigned blocks = (unsigned)((a.tiles + 7) / 8 * 8);
-  const size_t lds = (size_t)K * fs_pitch(TP);
+  const size_t lds = (size_t)K * fs_pitch(TP) + (size_t)K * 32;
   const bool dwnn = a.dw_act == ACT_RELU || a.dw_act == ACT_RELU6;
   const bool pwnn = OUT == OUT_I8 && (a.pw.act == ACT_RELU || a.pw.act == ACT_RELU6);
 #define PLHIP_FS_LAUNCH(DN, PN)                                                                                  \
@@ -300,9 +346,9 @@ static void launch_stream_o(const FusedArgs& a, int out, hipStream_t s) {
 
 void launch_fused_stream(const FusedArgs& a, int out, hipStream_t s) {
   // 112-wide: 4-row tiles of 448 pixels (2-row tiles fetched and cut every input row twice: 61 us, the two kernels 56)
-  if (a.w == 112) launch_stream_o<112, 32, 64, 448, 4, 4>(a, out, s);
-  else if (a.w == 56) launch_stream_o<56, 128, 128, 224, 4, 4>(a, out, s);
-  else launch_stream_o<28, 256, 256, 224, 4, 4>(a, out, s);
+  if (a.w == 112) launch_stream_o<112, 32, 64, 448, 4, 2>(a, out, s);
+  else if (a.w == 56) launch_stream_o<56, 128, 128, 224, 4, 2>(a, out, s);
+  else launch_stream_o<28, 256, 256, 224, 4, 2>(a, out, s);
 }
 
 }  // namespace plhip

@@ -900,6 +900,10 @@ extern "C" int plhip_debug_read_fw_stamps(void* dst_host, size_t bytes) {
   if (!dst_host) return -1;
   return plhip::debug_read_fw_stamps(dst_host, bytes);
 }
+extern "C" int plhip_debug_read_fs_stamps(void* dst_host, size_t bytes) {
+  if (!dst_host) return -1;
+  return plhip::debug_read_fs_stamps(dst_host, bytes);
+}
 // Diagnostics switches of the shipped library (declared in include/plhip.h).  NOTHING in the library reads the environment:
 // the A/B and timing knobs the kernels' launchers consult (plhip::knob) live in this table and change only
 // through plhip_debug_set; an unknown key is refused.  "fused_stamps" / "fused_exp": the fused kernel's timeline / timing experiments.

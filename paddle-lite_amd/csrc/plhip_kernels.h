@@ -173,6 +173,7 @@ bool fused_stream_supported(const FusedArgs& a);   // fused_dwpw_stream.hip: the
 void launch_fused_stream(const FusedArgs& a, int out, hipStream_t s);
 void debug_set_fused(int v);                        // bit 5 (32): timeline stamps
 int debug_read_fw_stamps(void* dst, size_t bytes);
+int debug_read_fs_stamps(void* dst, size_t bytes);  // the streaming kernel's
 
 int launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);  // 0 or -3
 // second-generation ring kernel (gemm_tr_i8.hip); false = shape outside it, the caller falls back
