@@ -333,6 +333,10 @@ def oracle_selfcheck(np, pred, net, cfg, images, out_var):
 
 def main():
     args = parse()
+    wd = os.environ.get("PLHIP_BENCH_WATCHDOG")  # seconds: dump every thread's Python stack and exit if still running by then
+    if wd:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(wd), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -514,13 +514,15 @@ __global__ __launch_bounds__(512, 2) void fused_dwpw14_kernel(FusedArgs a) {
 // plane, 128 | C <= 512 (whole rounds; the K x 128 activation image + the staging image fit the LDS), M = 256 or 512 (one or
 // two m tiles per wave), depthwise activation relu / relu6 / none / leaky, any pointwise activation.
 bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int dw, int out) {
-  if (!(kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1)) return false;
+  if (!(kh == 3 && kw == 3 && sh == sw && (sh == 1 || sh == 2) && dh == 1 && dw == 1)) return false;
   a->ones = 0x01010101u;
   a->stream = 0;
-  if (knob("FUSED_STREAM", 1) && fused_stream_supported(*a)) {  // the large planes: fused_dwpw_stream.hip
+  const int fs = knob("FUSED_STREAM", 1);  // 1: stride-1 and stride-2 shapes, 2: stride 1 only, 0: off
+  if (fs && (sh == 1 || fs == 1) && fused_stream_supported(*a)) {  // the large planes: fused_dwpw_stream.hip
     a->stream = 1;
     return true;
   }
+  if (sh != 1) return false;
   if (!(a->h == 14 && a->w == 14 && a->oh == 14 && a->ow == 14 && a->pt == 1 && a->pl == 1)) return false;
   if (a->C % 128 != 0 || a->C < 128 || a->C > 512) return false;
   if (a->pw.M != 256 && a->pw.M != 512) return false;

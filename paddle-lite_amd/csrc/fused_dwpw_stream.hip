@@ -50,7 +50,8 @@ int debug_read_fs_stamps(void* dst, size_t bytes) {
 
 // W: plane width; K, M: channels in / out; RS: output rows per strip (TR = 224 / W rows per tile, TR % RS == 0); PD: iterations
 // of operands in flight
-template <int W, int K, int M, int TP, int RS, int PD, int OUT, bool DWNN, bool PWNN>
+// S: stride of the depthwise stage (1 or 2; W and the tile are those of the OUTPUT plane, the input plane is S W wide)
+template <int W, int K, int M, int TP, int RS, int PD, int S, int OUT, bool DWNN, bool PWNN>
 __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kernel(FusedArgs a) {
   constexpr int FS_TP = TP, FS_NT = TP / 32, FS_PITCH = fs_pitch(TP);
   static_assert((FS_PITCH / 4) % 64 == 8 && FS_PITCH >= TP, "image pitch");
@@ -63,7 +64,10 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
   constexpr int NSPLIT = 4 / MSPLIT;                        // waves along the n tiles
   constexpr int MW = MT / MSPLIT;                           // m tiles per wave
   constexpr int NW = (FS_NT + NSPLIT - 1) / NSPLIT;         // n tiles per wave (the last split may own fewer)
-  constexpr int NIN = RS + 2;
+  constexpr int NIN = S == 1 ? RS + 2 : 2 * RS + 1;         // input rows of a strip
+  constexpr int ND = S == 1 ? 2 : 3;                        // dwords fetched per input row
+  constexpr int WI = S * W;                                 // input plane width
+  static_assert(S == 1 || S == 2, "stride");
   static_assert(FS_TP % W == 0 && TR % RS == 0 && W % 4 == 0 && K % 32 == 0 && M % 32 == 0 && MT % MSPLIT == 0, "geometry");
   const GemmArgs& g = a.pw;
   PLHIP_PRELOAD(a.x); PLHIP_PRELOAD(a.dw_w); PLHIP_PRELOAD(a.dw_scale); PLHIP_PRELOAD(a.dw_bias); PLHIP_PRELOAD(a.dw_act);
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
   const unsigned nb = (unsigned)a.tiles, per = (nb + 7) >> 3;
   const unsigned vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (vb >= nb) return;  // block-uniform
-  const int H = a.h, TPI = g.NT;  // tiles per image (launcher)
+  const int H = a.oh, TPI = g.NT;  // output rows; tiles per image (launcher)
   const int b = (int)(vb / (unsigned)TPI), ti = (int)(vb - (unsigned)b * TPI), tr0 = ti * TR;
   const int c = lane & 31, h = lane >> 5;
   const bool diag = (g.dbg & 32) != 0 && vb < 2048;
@@ -92,11 +96,17 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
   const uint32_t sel_hi = q == 0 ? 0x06050403u : (q == QW - 1 ? 0x0c0c0c07u : 0x07060504u);
   const float dw_hi2 = a.dw_act == ACT_RELU6 ? fminf(a.dw_alpha + a.dw_alpha, 254.f) : 254.f;
   const float dw_leak = a.dw_act == ACT_LEAKY ? a.dw_alpha : 1.f;
-  const uint32_t plane = (uint32_t)H * W;
+  const uint32_t plane = (uint32_t)H * W, plane_in = (uint32_t)a.h * WI;
+  // stride 2: a quad of 4 outputs reads input columns 8 q - 1 .. 8 q + 7.  The lane fetches the 12 aligned bytes from column
+  // 8 q - 4 (d0 d1 d2): output j's window (columns 8 q + 2 j - 1 .. + 1) is bytes 3 + 2 j .. of them: three v_alignbyte and,
+  // for j = 3, d2 itself against the filter row moved up one byte.  Column -1 (q = 0) is the left padding: masked.  No window
+  // crosses the right or the bottom border (even planes, pad 1).  The only bytes outside the tensor would be the 4 in front of
+  // its very first row: that one lane fetches from column 0 instead and moves its dwords up by one.
+  const uint32_t m0 = q == 0 ? 0xffffff00u : 0xffffffffu;
 
   // PD iterations of operands in flight (a ring of PD register sets): an iteration is ~100-150 VALU, a fetch from HBM under
   // load ~2 us: with one iteration ahead every wave waited for its rows (first form: 61 / 45 / 33 us for the three pairs)
-  uint32_t in[PD][NIN][2];  // row windows
+  uint32_t in[PD][NIN][ND];  // row windows
   // depthwise parameters of all K channels, once per block, into LDS: (w0 w1 w2 0 | w3 w4 w5 0 | w6 w7 w8 0 | 2 scale | 2 bias):
   // per iteration a lane then reads ONE 16-byte and one 4-byte LDS word instead of five global loads (the vector-memory
   // instructions were the startup cost of a block: 44 per wave, 6.7 k cycles to issue with four blocks per CU)
@@ -125,13 +135,22 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
     constexpr int it = decltype(it_c)::value, s = it % PD;
     int ch, strip, r0;
     task(it, ch, strip, r0);
-    const uint32_t off0 = (uint32_t)(b * K + ch) * plane + (uint32_t)r0 * W + colq;  // input row r0
-    const bool top = r0 == 0, bot = r0 + RS == H;
     const uint8_t* xs = reinterpret_cast<const uint8_t*>(a.x);
-    __builtin_memcpy(in[s][0], xs + (top ? off0 : off0 - W), 8);
+    if constexpr (S == 1) {
+      const uint32_t off0 = (uint32_t)(b * K + ch) * plane + (uint32_t)r0 * W + colq;  // input row r0
+      const bool top = r0 == 0, bot = r0 + RS == H;
+      __builtin_memcpy(in[s][0], xs + (top ? off0 : off0 - W), 8);
 #pragma unroll
-    for (int t = 1; t <= RS; ++t) __builtin_memcpy(in[s][t], xs + off0 + (t - 1) * W, 8);
-    __builtin_memcpy(in[s][RS + 1], xs + (bot ? off0 + (RS - 1) * W : off0 + RS * W), 8);
+      for (int t = 1; t <= RS; ++t) __builtin_memcpy(in[s][t], xs + off0 + (t - 1) * W, 8);
+      __builtin_memcpy(in[s][RS + 1], xs + (bot ? off0 + (RS - 1) * W : off0 + RS * W), 8);
+    } else {
+      const int off0 = (int)((uint32_t)(b * K + ch) * plane_in + (uint32_t)(2 * r0) * WI) + 8 * q - 4;  // input row 2 r0
+      const int o1 = off0 < 0 ? 0 : off0;  // (the tensor's first row, first quad)
+      __builtin_memcpy(in[s][0], xs + (r0 == 0 ? o1 : off0 - WI), 12);
+      __builtin_memcpy(in[s][1], xs + o1, 12);
+#pragma unroll
+      for (int t = 2; t < NIN; ++t) __builtin_memcpy(in[s][t], xs + off0 + (t - 1) * WI, 12);
+    }
   };
   auto compute = [&](auto it_c) __attribute__((always_inline)) {
     constexpr int it = decltype(it_c)::value, s = it % PD;
@@ -142,24 +161,50 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
     int dacc[RS][4];
     const v4i pv = *reinterpret_cast<const v4i*>(prm + ch * 32);
     const uint32_t wr[3] = {(uint32_t)pv[0], (uint32_t)pv[1], (uint32_t)pv[2]};  // packed filter rows (w0, w1, w2, 0)
-    const uint32_t w0t = wr[0] & zt, w2b = wr[2] & zb;
+    const uint32_t w0t = wr[0] & zt, w2b = S == 1 ? wr[2] & zb : wr[2];
+    const uint32_t wu[3] = {wr[0] << 8, wr[1] << 8, wr[2] << 8};  // (stride 2: the last output's window sits one byte up)
+    const uint32_t w0tu = w0t << 8;
+    const bool fix = S == 2 && b == 0 && ch == 0 && q == 0 && r0 == 0;
     const float dsc = __uint_as_float((uint32_t)pv[3]), dbi = __uint_as_float(*reinterpret_cast<const uint32_t*>(prm + ch * 32 + 16));
 #pragma unroll
     for (int t = 0; t < NIN; ++t) {
-      const uint32_t e0 = __builtin_amdgcn_perm(in[s][t][1], in[s][t][0], sel_lo), e1 = __builtin_amdgcn_perm(in[s][t][1], in[s][t][0], sel_hi);
       uint32_t win[4];
-      win[0] = e0;
-      win[1] = __builtin_amdgcn_alignbyte(e1, e0, 1);
-      win[2] = __builtin_amdgcn_alignbyte(e1, e0, 2);
-      win[3] = __builtin_amdgcn_alignbyte(e1, e0, 3);
+      if constexpr (S == 1) {
+        const uint32_t e0 = __builtin_amdgcn_perm(in[s][t][1], in[s][t][0], sel_lo), e1 = __builtin_amdgcn_perm(in[s][t][1], in[s][t][0], sel_hi);
+        win[0] = e0;
+        win[1] = __builtin_amdgcn_alignbyte(e1, e0, 1);
+        win[2] = __builtin_amdgcn_alignbyte(e1, e0, 2);
+        win[3] = __builtin_amdgcn_alignbyte(e1, e0, 3);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int o = t - r;
-        if (o < 0 || o >= RS) continue;
+        for (int r = 0; r < 3; ++r) {
+          const int o = t - r;
+          if (o < 0 || o >= RS) continue;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          dacc[o][jj] = r == 0 ? sdot4_first(win[jj], t == 0 ? w0t : wr[0])
-                               : __builtin_amdgcn_sdot4((int)win[jj], (int)(t == NIN - 1 ? w2b : wr[r]), dacc[o][jj], false);
+          for (int jj = 0; jj < 4; ++jj)
+            dacc[o][jj] = r == 0 ? sdot4_first(win[jj], t == 0 ? w0t : wr[0])
+                                 : __builtin_amdgcn_sdot4((int)win[jj], (int)(t == NIN - 1 ? w2b : wr[r]), dacc[o][jj], false);
+        }
+      } else {
+        uint32_t d0 = in[s][t][0], d1 = in[s][t][1], d2 = in[s][t][2];
+        if (t < 2) {  // the lane that fetched from column 0
+          d2 = fix ? d1 : d2;
+          d1 = fix ? d0 : d1;
+        }
+        win[0] = __builtin_amdgcn_alignbyte(d1, d0, 3) & m0;
+        win[1] = __builtin_amdgcn_alignbyte(d2, d1, 1);
+        win[2] = __builtin_amdgcn_alignbyte(d2, d1, 3);
+        win[3] = d2;  // against the filter row moved up one byte
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if ((t - r) & 1) continue;
+          const int o = (t - r) / 2;
+          if (t - r < 0 || o >= RS) continue;
+          const uint32_t f = t == 0 ? w0t : wr[r], fu = t == 0 ? w0tu : wu[r];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            dacc[o][jj] = r == 0 ? sdot4_first(win[jj], jj == 3 ? fu : f)
+                                 : __builtin_amdgcn_sdot4((int)win[jj], (int)(jj == 3 ? fu : f), dacc[o][jj], false);
+        }
       }
     }
 #pragma unroll
@@ -310,15 +355,16 @@ __global__ __launch_bounds__(256, M >= 256 ? 2 : 3) void fused_dwpw_stream_kerne
 // shapes of the streaming kernel: (W, K, M) = (112, 32, 64), (56, 128, 128), (28, 256, 256): MobileNetV1's stride-1 pairs on
 // the large planes; 3x3, stride 1, dilation 1, pad 1, square planes
 bool fused_stream_supported(const FusedArgs& a) {
-  if (!(a.h == a.w && a.oh == a.h && a.ow == a.w && a.pt == 1 && a.pl == 1 && a.stride == 1)) return false;
-  if (a.n < 1 || (long)a.n * a.C * a.h * a.w >= ((long)1 << 31) - 65536 || (long)a.n * a.pw.M * a.h * a.w >= ((long)1 << 31)) return false;
+  if (!(a.h == a.w && a.oh == a.ow && a.pt == 1 && a.pl == 1 && (a.stride == 1 || a.stride == 2) && a.h == a.oh * a.stride)) return false;
+  if (a.n < 1 || (long)a.n * a.C * a.h * a.w >= ((long)1 << 31) - 65536 || (long)a.n * a.pw.M * a.oh * a.ow >= ((long)1 << 31)) return false;
+  if (a.stride == 2) return (a.ow == 56 && a.C == 64 && a.pw.M == 128) || (a.ow == 28 && a.C == 128 && a.pw.M == 256);
   return (a.w == 112 && a.C == 32 && a.pw.M == 64) || (a.w == 56 && a.C == 128 && a.pw.M == 128) || (a.w == 28 && a.C == 256 && a.pw.M == 256);
 }
 
-template <int W, int K, int M, int TP, int RS, int PD, int OUT>
+template <int W, int K, int M, int TP, int RS, int PD, int S, int OUT>
 static void launch_stream_t(FusedArgs a, hipStream_t s) {
   constexpr int TR = TP / W;
-  a.pw.NT = (a.h + TR - 1) / TR;  // tiles per image
+  a.pw.NT = (a.oh + TR - 1) / TR;  // tiles per image
   a.tiles = a.n * a.pw.NT;
   const unsigned blocks = (unsigned)((a.tiles + 7) / 8 * 8);
   const size_t lds = (size_t)K * fs_pitch(TP) + (size_t)K * 32;
@@ -326,7 +372,7 @@ static void launch_stream_t(FusedArgs a, hipStream_t s) {
   const bool pwnn = OUT == OUT_I8 && (a.pw.act == ACT_RELU || a.pw.act == ACT_RELU6);
 #define PLHIP_FS_LAUNCH(DN, PN)                                                                                  \
   do {                                                                                                           \
-    auto kfn = fused_dwpw_stream_kernel<W, K, M, TP, RS, PD, OUT, DN, PN>;                                               \
+    auto kfn = fused_dwpw_stream_kernel<W, K, M, TP, RS, PD, S, OUT, DN, PN>;                                               \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, s, a);                                                 \
   } while (0)
@@ -337,16 +383,18 @@ static void launch_stream_t(FusedArgs a, hipStream_t s) {
 #undef PLHIP_FS_LAUNCH
 }
 
-template <int W, int K, int M, int TP, int RS, int PD>
+template <int W, int K, int M, int TP, int RS, int PD, int S = 1>
 static void launch_stream_o(const FusedArgs& a, int out, hipStream_t s) {
-  if (out == OUT_I32) launch_stream_t<W, K, M, TP, RS, PD, OUT_I32>(a, s);
-  else if (out == OUT_F32) launch_stream_t<W, K, M, TP, RS, PD, OUT_F32>(a, s);
-  else launch_stream_t<W, K, M, TP, RS, PD, OUT_I8>(a, s);
+  if (out == OUT_I32) launch_stream_t<W, K, M, TP, RS, PD, S, OUT_I32>(a, s);
+  else if (out == OUT_F32) launch_stream_t<W, K, M, TP, RS, PD, S, OUT_F32>(a, s);
+  else launch_stream_t<W, K, M, TP, RS, PD, S, OUT_I8>(a, s);
 }
 
 void launch_fused_stream(const FusedArgs& a, int out, hipStream_t s) {
   // 112-wide: 4-row tiles of 448 pixels (2-row tiles fetched and cut every input row twice: 61 us, the two kernels 56)
-  if (a.w == 112) launch_stream_o<112, 32, 64, 448, 4, 2>(a, out, s);
+  if (a.stride == 2 && a.ow == 56) launch_stream_o<56, 64, 128, 224, 4, 2, 2>(a, out, s);
+  else if (a.stride == 2) launch_stream_o<28, 128, 256, 224, 4, 2, 2>(a, out, s);
+  else if (a.w == 112) launch_stream_o<112, 32, 64, 448, 4, 2>(a, out, s);
   else if (a.w == 56) launch_stream_o<56, 128, 128, 224, 4, 2>(a, out, s);
   else launch_stream_o<28, 256, 256, 224, 4, 2>(a, out, s);
 }

@@ -57,10 +57,15 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         (2, 256, 28, 28, 1, (1, 1, 1, 1), 256, 1, 1, True),     # dw6 / pw6: 8-row tiles, the last tile of an image half empty
         (1, 128, 56, 56, 1, (1, 1, 1, 1), 128, 0, 4, False),    # no depthwise activation, leaky pointwise, fp32 output
         (1, 32, 112, 112, 1, (1, 1, 1, 1), 64, 4, 0, True),     # leaky depthwise, no pointwise activation
+        # ... and its stride-2 form (12 aligned bytes per input row; the tensor's first quad fetches from column 0)
+        (2, 64, 112, 112, 2, (1, 1, 1, 1), 128, 1, 1, True),    # dw3 / pw3
+        (3, 128, 56, 56, 2, (1, 1, 1, 1), 256, 2, 2, True),     # dw5 / pw5, relu6 both: the last tile of an image half empty
+        (1, 64, 112, 112, 2, (1, 1, 1, 1), 128, 0, 4, False),   # no depthwise activation, leaky pointwise, fp32 output
+        (1, 128, 56, 56, 2, (1, 1, 1, 1), 256, 4, 0, True),     # leaky depthwise
         # outside the fused path (the predictor runs the two kernels): reported as unsupported
         (2, 32, 16, 16, 1, (1, 1, 1, 1), 64, 1, 1, True),
         (2, 64, 16, 16, 2, (1, 1, 1, 1), 128, 1, 1, True),
-        (2, 64, 112, 112, 2, (1, 1, 1, 1), 128, 1, 1, True),    # stride 2 on a large plane
+        (2, 64, 112, 112, 2, (0, 1, 0, 1), 128, 1, 1, True),    # stride 2 with the padding on the other side
         (2, 64, 56, 56, 1, (1, 1, 1, 1), 128, 1, 1, True),      # a large plane with another channel count
         (2, 96, 7, 7, 1, (1, 1, 1, 1), 160, 1, 1, False),
         (1, 40, 9, 13, 2, (0, 1, 1, 0), 33, 0, 4, True),
@@ -75,7 +80,7 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         ran.append(_case(gpu_ctx, capi, plref, rng, n, c, h, w, st, pad, m, da, pa, i8, pw_alpha=(6.0 if pa == 2 else 0.3),
                          dw_alpha=(6.0 if da == 2 else (0.2 if da == 4 else 0.0))))
     print("fused cases run:", ran)
-    assert ran[:12] == [True] * 12 and not any(ran[12:]), ran
+    assert ran[:16] == [True] * 16 and not any(ran[16:]), ran
 
 
 def test_fused_unsupported_shapes_are_reported(gpu_ctx, pkg):

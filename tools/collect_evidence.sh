@@ -49,8 +49,11 @@ timeout -k 10 200 python tools/opbench.py fused 2>&1 | cut -c1-110 | grep "fused
 timeout -k 10 100 python tools/fused_timeline.py > $O/fused_timeline_b128.txt 2>&1 || exit 1
 timeout -k 10 100 python tools/fused_timeline.py --batch 256 > $O/fused_timeline_b256.txt 2>&1 || exit 1
 for e in 1 2 3 19 4; do timeout -k 10 100 python tools/fused_timeline.py --exp $e > $O/fused_timeline_exp$e.txt 2>&1 || exit 1; done
+for cfg in "128 128 56" "32 64 112" "256 256 28"; do set -- $cfg; timeout -k 10 100 python tools/stream_timeline.py --c $1 --m $2 --hw $3 > $O/stream_timeline_$3.txt 2>&1 || exit 1; done
 [ -x tools/_probe_coexec ] && ./tools/_probe_coexec > $O/probe_coexec.txt 2>&1
 [ -x tools/_probe_rtz ] && ./tools/_probe_rtz > $O/probe_cvt_rtz.txt 2>&1
+PLHIP_FUSED_STREAM=0 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_stream_off.json 2>/dev/null || exit 1
+PLHIP_FUSED_STREAM=0 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_stream_off_inflight1.json 2>/dev/null || exit 1
 PLHIP_BENCH_FUSE_DWPW=0 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_dwpw_off.json 2>/dev/null || exit 1
 PLHIP_BENCH_FUSE_DWPW=0 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_dwpw_off_inflight1.json 2>/dev/null || exit 1
 timeout -k 10 200 python tools/opbench.py all --batch 256 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench_b256.txt || exit 1
@@ -82,6 +85,6 @@ timeout -k 10 400 python bench.py --config c4 --layer-table > $O/bench_c4.json 2
 timeout -k 10 400 python bench.py --config c5 --layer-table > $O/bench_c5.json 2> $O/layer_table_c5.txt || exit 1
 timeout -k 10 300 python bench.py --config c2 > $O/bench_c2.json 2>/dev/null || exit 1
 # the N > 1 data path on one GPU: one rank, RCCL broadcast / scatter / per-step all_gather
-PLHIP_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_force_dist.json 2> $O/force_dist.err || { tail -5 $O/force_dist.err; exit 1; }
+PLHIP_BENCH_FORCE_DIST=1 PLHIP_BENCH_WATCHDOG=200 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_force_dist.json 2> $O/force_dist.err || { echo "force_dist rc=$?"; tail -30 $O/force_dist.err; exit 1; }
 timeout -k 10 100 python tools/c2bench.py > $O/c2bench.txt 2>&1 || exit 1
 tail -c 400 $O/bench.json

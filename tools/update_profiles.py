@@ -35,7 +35,8 @@ for f in ("bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.j
           "patch_timeline_res5a_s2.txt", "patch_timeline_c2.txt", "patch_timeline_res2.txt", "patch_timeline_res4.txt",
           "opbench_fused.txt", "fused_timeline_b128.txt", "fused_timeline_b256.txt", "fused_timeline_exp1.txt", "fused_timeline_exp2.txt",
           "fused_timeline_exp3.txt", "fused_timeline_exp19.txt", "fused_timeline_exp4.txt", "probe_coexec.txt", "probe_cvt_rtz.txt",
-          "bench_dwpw_off.json", "bench_dwpw_off_inflight1.json"):
+          "bench_dwpw_off.json", "bench_dwpw_off_inflight1.json", "bench_stream_off.json", "bench_stream_off_inflight1.json",
+          "stream_timeline_56.txt", "stream_timeline_112.txt", "stream_timeline_28.txt"):
     if os.path.exists(os.path.join(E, f)):
         cp(f, f)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
