@@ -62,6 +62,10 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         (3, 128, 56, 56, 2, (1, 1, 1, 1), 256, 2, 2, True),     # dw5 / pw5, relu6 both: the last tile of an image half empty
         (1, 64, 112, 112, 2, (1, 1, 1, 1), 128, 0, 4, False),   # no depthwise activation, leaky pointwise, fp32 output
         (1, 128, 56, 56, 2, (1, 1, 1, 1), 256, 4, 0, True),     # leaky depthwise
+        # ... on the 14-wide plane: 16-slot rows (2 junk), half-image tiles, the output channels in two passes, 14-byte row stores
+        (3, 256, 28, 28, 2, (1, 1, 1, 1), 512, 1, 1, True),     # dw7 / pw7
+        (1, 256, 28, 28, 2, (1, 1, 1, 1), 512, 2, 0, False),    # one image (its first and last lanes fetch shifted), fp32 output
+        (2, 256, 28, 28, 2, (1, 1, 1, 1), 512, 4, 4, True),     # leaky both
         # outside the fused path (the predictor runs the two kernels): reported as unsupported
         (2, 32, 16, 16, 1, (1, 1, 1, 1), 64, 1, 1, True),
         (2, 64, 16, 16, 2, (1, 1, 1, 1), 128, 1, 1, True),
@@ -69,7 +73,7 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         (2, 64, 56, 56, 1, (1, 1, 1, 1), 128, 1, 1, True),      # a large plane with another channel count
         (2, 96, 7, 7, 1, (1, 1, 1, 1), 160, 1, 1, False),
         (1, 40, 9, 13, 2, (0, 1, 1, 0), 33, 0, 4, True),
-        (5, 256, 28, 28, 2, (1, 1, 1, 1), 512, 2, 2, True),
+        (5, 256, 28, 28, 2, (1, 1, 1, 1), 256, 2, 2, True),
         (1, 1024, 7, 7, 1, (1, 1, 1, 1), 1024, 1, 1, False),
         (1, 16, 112, 112, 1, (1, 1, 1, 1), 24, 1, 0, True),
         (2, 512, 14, 14, 1, (0, 1, 1, 1), 512, 1, 1, True),     # top padding 0: outside
@@ -80,7 +84,7 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         ran.append(_case(gpu_ctx, capi, plref, rng, n, c, h, w, st, pad, m, da, pa, i8, pw_alpha=(6.0 if pa == 2 else 0.3),
                          dw_alpha=(6.0 if da == 2 else (0.2 if da == 4 else 0.0))))
     print("fused cases run:", ran)
-    assert ran[:16] == [True] * 16 and not any(ran[16:]), ran
+    assert ran[:19] == [True] * 19 and not any(ran[19:]), ran
 
 
 def test_fused_unsupported_shapes_are_reported(gpu_ctx, pkg):
