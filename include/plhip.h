@@ -34,7 +34,10 @@ typedef enum {
 } plhip_status;
 
 /* Output kind.  I32_ACC exists for the bit-exact accumulator check only. */
-typedef enum { PLHIP_OUT_I32_ACC = 0, PLHIP_OUT_F32 = 1, PLHIP_OUT_I8 = 2 } plhip_out_kind;
+/* PLHIP_OUT_F32_GAP: the fp32 output averaged over each output plane, y = [n][cout] floats: the instruction pair
+ * conv2d[fp32_out] -> pool2d(avg, global_pooling) (lite/backends/arm/math/pooling.cc:1006- pooling_global_avg) in the launch that
+ * produces the plane; accepted by plhip_dwpw_fused_int8 / plhip_dwpw_fused_supported only (every other entry refuses it). */
+typedef enum { PLHIP_OUT_I32_ACC = 0, PLHIP_OUT_F32 = 1, PLHIP_OUT_I8 = 2, PLHIP_OUT_F32_GAP = 3 } plhip_out_kind;
 
 /* Activation codes == lite_api::ActivationType, lite/api/paddle_place.h:101-105. */
 typedef enum { PLHIP_ACT_NONE = 0, PLHIP_ACT_RELU = 1, PLHIP_ACT_RELU6 = 2, PLHIP_ACT_LEAKY_RELU = 4 } plhip_act;
@@ -214,6 +217,7 @@ plhip_status plhip_selftest(plhip_ctx* ctx);
 int plhip_debug_set(const char* key, int value);
 int plhip_debug_read_fw_stamps(void* dst_host, size_t bytes);
 int plhip_debug_read_fs_stamps(void* dst_host, size_t bytes); /* the streaming fused kernel: [tile < 2048][wave 4][8] */
+int plhip_debug_read_f7_stamps(void* dst_host, size_t bytes); /* the small-plane fused kernel: [block < 1024][wave 8][8] */
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLHIP_LIB_PATH") or os.path.join(_HERE, "libplhip.so")  # override: diagnostic builds only (tools/slp_hazard_variants.py)
 
 OUT_I32, OUT_F32, OUT_I8 = 0, 1, 2
+OUT_F32_GAP = 3  # plhip_dwpw_fused_int8 only: the fp32 output averaged over each plane, [n][cout]
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 4
 _OUT_DTYPE = {OUT_I32: np.int32, OUT_F32: np.float32, OUT_I8: np.int8}
 
@@ -26,7 +27,7 @@ EXPORTS = [
     "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
     "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
     "plhip_pool2d_f32", "plhip_pool2d_max_i8", "plhip_elementwise_add_f32", "plhip_selftest",
-    "plhip_debug_set", "plhip_debug_read_fw_stamps", "plhip_debug_read_fs_stamps",
+    "plhip_debug_set", "plhip_debug_read_fw_stamps", "plhip_debug_read_fs_stamps", "plhip_debug_read_f7_stamps",
 ]
 
 
@@ -73,7 +74,7 @@ _lib = None
 # bench.py prints the dict in its JSON line, so a measurement taken with a knob says so.
 KNOBS = ("STEM_MFMA", "CONV_PATCH", "CONV_PATCH_S2", "PATCH_DEBUG", "PATCH_DELAY", "STEM7", "DW_STAGE", "DW_STAGE_NP2", "DW_FASTV",
          "DW5_DIRECT", "DW_RS1", "DW_RS2", "GEMM_VARIANT", "GEMM_AREG", "GEMM_MA", "GEMM_DEBUG", "SUBSAMPLE_1X1", "GEMM_TR", "TR_DELAY",
-         "TR_CFG", "GEMM_WIDE", "WIDE_NTT", "FC_MFMA", "IMPLICIT_GEMM", "FUSED_STREAM")
+         "TR_CFG", "GEMM_WIDE", "WIDE_NTT", "FC_MFMA", "IMPLICIT_GEMM", "FUSED_STREAM", "FUSED_SMALL")
 KNOBS_SET = {}
 
 
@@ -276,7 +277,7 @@ class Context:
         dy = self.malloc(d_dw.n * cout * oh * ow * esz)
         self.check(self.L.plhip_dwpw_fused_int8(self.h, C.byref(d_dw), dx, dwd, dsd, dbd, cout, dwp, dsp, dbp, pw_act, pw_alpha,
                                                 dy, out_kind), "dwpw_fused")
-        y = self.to_host(dy, (d_dw.n, cout, oh, ow), _OUT_DTYPE[out_kind])
+        y = self.to_host(dy, (d_dw.n, cout, 1, 1), np.float32) if out_kind == OUT_F32_GAP else self.to_host(dy, (d_dw.n, cout, oh, ow), _OUT_DTYPE[out_kind])
         for p in [dx, dwd, dsd, dwp_raw, dwp, dy] + ([dbd] if b_dw is not None else []) + ([dsp] if s_pw is not None else []) + \
                 ([dbp] if b_pw is not None else []):
             self.free(p)

@@ -517,11 +517,16 @@ bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int d
   if (!(kh == 3 && kw == 3 && sh == sw && (sh == 1 || sh == 2) && dh == 1 && dw == 1)) return false;
   a->ones = 0x01010101u;
   a->stream = 0;
-  const int fs = knob("FUSED_STREAM", 1);  // 1: stride-1 and stride-2 shapes, 2: stride 1 only, 0: off
-  if (fs && (sh == 1 || fs == 1) && fused_stream_supported(*a)) {  // the large planes: fused_dwpw_stream.hip
+  const int fs = knob("FUSED_STREAM", 1);  // 1: every shape of the streaming kernel, 2: stride 1 only, 3: not the 14-wide plane, 0: off
+  if (fs && (sh == 1 || fs != 2) && !(fs == 3 && a->ow == 14) && fused_stream_supported(*a)) {  // the large planes: fused_dwpw_stream.hip
     a->stream = 1;
     return true;
   }
+  if (knob("FUSED_SMALL", 1) && fused_small_supported(*a)) {  // the 7 x 7 planes: fused_dwpw_small.hip
+    a->stream = 2;
+    return true;
+  }
+  if (out == OUT_GAP) return false;  // the plane average: the small-plane kernel only
   if (sh != 1) return false;
   if (!(a->h == 14 && a->w == 14 && a->oh == 14 && a->ow == 14 && a->pt == 1 && a->pl == 1)) return false;
   if (a->C % 128 != 0 || a->C < 128 || a->C > 512) return false;
@@ -601,6 +606,10 @@ static void launch_fused_t(const FusedArgs& a, hipStream_t s) {
 void launch_fused_dwpw(const FusedArgs& a_in, int out, hipStream_t s) {
   FusedArgs a = a_in;
   a.pw.dbg = g_fw_debug;
+  if (a.stream == 2) {
+    launch_fused_small(a, out, s);
+    return;
+  }
   if (a.stream) {
     launch_fused_stream(a, out, s);
     return;

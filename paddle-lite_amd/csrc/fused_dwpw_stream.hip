@@ -173,7 +173,10 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
     const uint32_t zt = r0 == 0 ? 0u : 0xffffffffu, zb = r0 + RS == H ? 0u : 0xffffffffu;  // the strip's first / last input row outside the image
     // image address of (channel, strip row 0, quad); the lanes beyond the last group write into a sink behind the parameters
     // (a predicated store splits the body into basic blocks: an exec save / restore per store and nothing scheduled across)
-    const uint32_t ldsw = active ? (uint32_t)ch * FS_PITCH + (uint32_t)(strip * RS) * RP + 4 * q : (uint32_t)(K * FS_PITCH + K * 32) + 4 * (lane & 7);
+    // (not in the 255-register forms: 256 -> 256 @28 went 28.3 -> 33.8 us with it)
+    constexpr bool SINK = M / MP < 256;
+    const uint32_t ldsa = (uint32_t)ch * FS_PITCH + (uint32_t)(strip * RS) * RP + 4 * q;
+    const uint32_t ldsw = SINK && !active ? (uint32_t)(K * FS_PITCH + K * 32) + 4 * (lane & 7) : ldsa;
     int dacc[RS][4];
     const v4i pv = *reinterpret_cast<const v4i*>(prm + ch * 32);
     const uint32_t wr[3] = {(uint32_t)pv[0], (uint32_t)pv[1], (uint32_t)pv[2]};  // packed filter rows (w0, w1, w2, 0)
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
     for (int o = 0; o < RS; ++o) {
       const uint32_t pk = DWNN ? requant4_nn_rtz(dacc[o], dsc, dbi, dw_hi2, a.ones)
                                : dw_requant4<ACT_LEAKY>(dacc[o], dsc, dbi, dw_leak, -254.f, 254.f);
-      *reinterpret_cast<uint32_t*>(fs_lds + ldsw + o * RP) = pk;
+      if (SINK || active) *reinterpret_cast<uint32_t*>(fs_lds + ldsw + o * RP) = pk;
     }
   };
   auto prime = [&](auto self, auto it_c) __attribute__((always_inline)) -> void {

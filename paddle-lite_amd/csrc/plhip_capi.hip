@@ -613,6 +613,8 @@ plhip_status plhip_depthwise_conv_int8(plhip_ctx* ctx, const plhip_conv_desc* d,
   if (!conv_geom(d, &g)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_depthwise_conv_int8: bad conv descriptor");
   if (d->groups != d->cin || d->cin != d->cout)
     return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_depthwise_conv_int8: needs groups == cin == cout");
+  if (out != PLHIP_OUT_I32_ACC && out != PLHIP_OUT_F32 && out != PLHIP_OUT_I8)
+    return fail(ctx, PLHIP_ERR_INVALID, "plhip_depthwise_conv_int8: bad out kind");
   if (out != PLHIP_OUT_I32_ACC && !scale) return fail(ctx, PLHIP_ERR_INVALID, "plhip_depthwise_conv_int8: scale required");
   if (d->act != PLHIP_ACT_NONE && d->act != PLHIP_ACT_RELU && d->act != PLHIP_ACT_RELU6 && d->act != PLHIP_ACT_LEAKY_RELU)
     return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_depthwise_conv_int8: unsupported activation");
@@ -717,6 +719,8 @@ plhip_status plhip_dwpw_fused_int8(plhip_ctx* ctx, const plhip_conv_desc* dw, co
                                    plhip_out_kind out) {
   if (!ctx || !dw || !x || !dw_w_oihw || !dw_scale || !pw_w_packed || !y || pw_cout < 1)
     return fail(ctx, PLHIP_ERR_INVALID, "plhip_dwpw_fused_int8: null / bad argument");
+  if (out != PLHIP_OUT_I32_ACC && out != PLHIP_OUT_F32 && out != PLHIP_OUT_I8 && out != PLHIP_OUT_F32_GAP)
+    return fail(ctx, PLHIP_ERR_INVALID, "plhip_dwpw_fused_int8: bad out kind");
   if (out != PLHIP_OUT_I32_ACC && !pw_scale) return fail(ctx, PLHIP_ERR_INVALID, "plhip_dwpw_fused_int8: pw_scale required");
   plhip::FusedArgs a;
   const char* why;
@@ -904,6 +908,10 @@ extern "C" int plhip_debug_read_fs_stamps(void* dst_host, size_t bytes) {
   if (!dst_host) return -1;
   return plhip::debug_read_fs_stamps(dst_host, bytes);
 }
+extern "C" int plhip_debug_read_f7_stamps(void* dst_host, size_t bytes) {
+  if (!dst_host) return -1;
+  return plhip::debug_read_f7_stamps(dst_host, bytes);
+}
 // Diagnostics switches of the shipped library (declared in include/plhip.h).  NOTHING in the library reads the environment:
 // the A/B and timing knobs the kernels' launchers consult (plhip::knob) live in this table and change only
 // through plhip_debug_set; an unknown key is refused.  "fused_stamps" / "fused_exp": the fused kernel's timeline / timing experiments.
@@ -915,7 +923,7 @@ Knob g_knobs[] = {
     {"STEM7", 0, false}, {"DW_STAGE", 0, false}, {"DW_STAGE_NP2", 0, false}, {"DW_FASTV", 0, false}, {"DW5_DIRECT", 0, false},
     {"DW_RS1", 0, false}, {"DW_RS2", 0, false}, {"GEMM_VARIANT", 0, false}, {"GEMM_AREG", 0, false}, {"GEMM_MA", 0, false},
     {"GEMM_DEBUG", 0, false}, {"SUBSAMPLE_1X1", 0, false}, {"GEMM_TR", 0, false}, {"TR_DELAY", 0, false}, {"TR_CFG", 0, false},
-    {"GEMM_WIDE", 0, false}, {"WIDE_NTT", 0, false}, {"FC_MFMA", 0, false}, {"IMPLICIT_GEMM", 0, false}, {"FUSED_STREAM", 0, false}};
+    {"GEMM_WIDE", 0, false}, {"WIDE_NTT", 0, false}, {"FC_MFMA", 0, false}, {"IMPLICIT_GEMM", 0, false}, {"FUSED_STREAM", 0, false}, {"FUSED_SMALL", 0, false}};
 }  // namespace
 int knob(const char* name, int dflt) {
   for (const Knob& k : g_knobs)

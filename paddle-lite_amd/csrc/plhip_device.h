@@ -15,7 +15,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-enum { OUT_I32 = 0, OUT_F32 = 1, OUT_I8 = 2 };
+enum { OUT_I32 = 0, OUT_F32 = 1, OUT_I8 = 2, OUT_GAP = 3 };  // OUT_GAP: fp32, averaged over the plane (fused_dwpw_small.hip only)
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2, ACT_LEAKY = 4 };
 
 __device__ __forceinline__ float epilogue_f32(int acc, float scale, float bias, int act, float alpha) {

@@ -171,9 +171,12 @@ bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int d
 void launch_fused_dwpw(const FusedArgs& a, int out, hipStream_t s);
 bool fused_stream_supported(const FusedArgs& a);   // fused_dwpw_stream.hip: the 112 / 56 / 28-wide stride-1 pairs
 void launch_fused_stream(const FusedArgs& a, int out, hipStream_t s);
+bool fused_small_supported(const FusedArgs& a);    // fused_dwpw_small.hip: the 7 x 7 planes (512 -> 1024 stride 2, 1024 -> 1024)
+void launch_fused_small(const FusedArgs& a, int out, hipStream_t s);
 void debug_set_fused(int v);                        // bit 5 (32): timeline stamps
 int debug_read_fw_stamps(void* dst, size_t bytes);
 int debug_read_fs_stamps(void* dst, size_t bytes);  // the streaming kernel's
+int debug_read_f7_stamps(void* dst, size_t bytes);  // the small-plane kernel's
 
 int launch_gemm_i8(const GemmArgs& g, int ma, int out, bool vec_store, bool aligned_loads, hipStream_t s);  // 0 or -3
 // second-generation ring kernel (gemm_tr_i8.hip); false = shape outside it, the caller falls back

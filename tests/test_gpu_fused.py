@@ -66,6 +66,12 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         (3, 256, 28, 28, 2, (1, 1, 1, 1), 512, 1, 1, True),     # dw7 / pw7
         (1, 256, 28, 28, 2, (1, 1, 1, 1), 512, 2, 0, False),    # one image (its first and last lanes fetch shifted), fp32 output
         (2, 256, 28, 28, 2, (1, 1, 1, 1), 512, 4, 4, True),     # leaky both
+        # the 7 x 7 planes (fused_dwpw_small.hip): one image per block pair, lane = (channel, output row)
+        (3, 512, 14, 14, 2, (1, 1, 1, 1), 1024, 1, 1, True),    # dw13 / pw13
+        (2, 1024, 7, 7, 1, (1, 1, 1, 1), 1024, 1, 1, False),    # dw14 / pw14: fp32 output (what the pool reads)
+        (1, 1024, 7, 7, 1, (1, 1, 1, 1), 1024, 2, 2, True),     # one image (its first lane fetches shifted), relu6 both, int8 output
+        (1, 512, 14, 14, 2, (1, 1, 1, 1), 1024, 4, 0, False),   # leaky depthwise, fp32 output
+        (5, 512, 14, 14, 2, (1, 1, 1, 1), 1024, 0, 4, True),    # 10 blocks on 16: ragged XCD shares; leaky pointwise
         # outside the fused path (the predictor runs the two kernels): reported as unsupported
         (2, 32, 16, 16, 1, (1, 1, 1, 1), 64, 1, 1, True),
         (2, 64, 16, 16, 2, (1, 1, 1, 1), 128, 1, 1, True),
@@ -74,7 +80,7 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         (2, 96, 7, 7, 1, (1, 1, 1, 1), 160, 1, 1, False),
         (1, 40, 9, 13, 2, (0, 1, 1, 0), 33, 0, 4, True),
         (5, 256, 28, 28, 2, (1, 1, 1, 1), 256, 2, 2, True),
-        (1, 1024, 7, 7, 1, (1, 1, 1, 1), 1024, 1, 1, False),
+        (1, 512, 7, 7, 1, (1, 1, 1, 1), 1024, 1, 1, False),
         (1, 16, 112, 112, 1, (1, 1, 1, 1), 24, 1, 0, True),
         (2, 512, 14, 14, 1, (0, 1, 1, 1), 512, 1, 1, True),     # top padding 0: outside
         (2, 192, 14, 14, 1, (1, 1, 1, 1), 256, 1, 1, True),     # C % 128 != 0: outside
@@ -84,7 +90,42 @@ def test_fused_matches_two_stage_oracle(gpu_ctx, pkg, plref):
         ran.append(_case(gpu_ctx, capi, plref, rng, n, c, h, w, st, pad, m, da, pa, i8, pw_alpha=(6.0 if pa == 2 else 0.3),
                          dw_alpha=(6.0 if da == 2 else (0.2 if da == 4 else 0.0))))
     print("fused cases run:", ran)
-    assert ran[:19] == [True] * 19 and not any(ran[19:]), ran
+    assert ran[:24] == [True] * 24 and not any(ran[24:]), ran
+
+
+def test_fused_pair_with_the_global_average_as_output(gpu_ctx, pkg, plref):
+    """PLHIP_OUT_F32_GAP: the pair's fp32 output averaged over each 7 x 7 plane in the launch that produces it = the instructions
+    conv2d[fp32_out] -> pool2d(avg, global) of the reference program (pooling.cc:1006-): equal to the oracle's global average of
+    the oracle's fp32 output within 1e-5 (the sum's order differs; the values summed are the bit-identical fp32 outputs)."""
+    import ctypes
+    capi = pkg.capi
+    rng = np.random.default_rng(301)
+    for (n, c, hw, st, m, dw_act, pw_act) in [(2, 1024, 7, 1, 1024, 1, 1), (3, 512, 14, 2, 1024, 1, 0), (1, 1024, 7, 1, 1024, 2, 4)]:
+        x = rng.integers(-127, 128, (n, c, hw, hw)).astype(np.int8)
+        w_dw = rng.integers(-127, 128, (c, 1, 3, 3)).astype(np.int8)
+        w_pw = rng.integers(-127, 128, (m, c, 1, 1)).astype(np.int8)
+        b_dw = rng.uniform(-1, 1, c).astype(np.float32)
+        b_pw = rng.uniform(-1, 1, m).astype(np.float32)
+        ws_dw = ((1 + np.arange(c) % 7) / 127.0 / 4.0).astype(np.float32)
+        ws_pw = ((1 + np.arange(m) % 5) / 127.0 / 4.0).astype(np.float32)
+        dw_alpha = 6.0 if dw_act == 2 else 0.0
+        in_s, mid_s = 1 / 127.0, (9 / 127.0 if dw_act != 2 else dw_alpha / 127.0)
+        sd = plref.shape(n, c, hw, hw, c, 3, 3, (1, 1, 1, 1), (st, st), (1, 1), c)
+        oh, ow = plref.out_dims(sd)
+        s1, b1, a1 = plref.fold_scales(1, in_s, ws_dw, mid_s, b_dw, c, dw_act, dw_alpha)
+        d_ref, _ = plref.conv2d(sd, x, w_dw, b_dw, in_s, ws_dw, mid_s, dw_act, dw_alpha, True)
+        sp = plref.shape(n, c, oh, ow, m, 1, 1, (0, 0, 0, 0), (1, 1), (1, 1), 1)
+        y_ref, _ = plref.conv2d(sp, d_ref, w_pw, b_pw, mid_s, ws_pw, 1.0, pw_act, 0.3, False)
+        s2, b2, a2 = plref.fold_scales(0, mid_s, ws_pw, 1.0, b_pw, m, pw_act, 0.3)
+        want = y_ref.astype(np.float64).mean(axis=(2, 3)).astype(np.float32).reshape(n, m, 1, 1)
+        d_dw = capi.conv_desc(n, c, hw, hw, c, 3, 3, (1, 1, 1, 1), (st, st), (1, 1), c, dw_act, a1)
+        assert gpu_ctx.L.plhip_dwpw_fused_supported(ctypes.byref(d_dw), m, capi.OUT_F32_GAP) == 1
+        got = gpu_ctx.dwpw_fused(d_dw, x, w_dw, s1, b1, w_pw, s2, b2, pw_act, a2, capi.OUT_F32_GAP)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    # the planes of the other fused kernels have no averaged form
+    d14 = capi.conv_desc(2, 512, 14, 14, 512, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 512, 1, 0.0)
+    assert gpu_ctx.L.plhip_dwpw_fused_supported(ctypes.byref(d14), 512, capi.OUT_F32_GAP) == 0
+    assert gpu_ctx.L.plhip_dwpw_fused_supported(ctypes.byref(d14), 512, capi.OUT_F32) == 1
 
 
 def test_fused_unsupported_shapes_are_reported(gpu_ctx, pkg):

@@ -425,8 +425,8 @@ def test_int8_max_pool_commutes_with_calib(gpu_ctx, plref):
 @pytest.mark.parametrize("which,batch,mode", [("mobilenet_v1", 2, None), ("mobilenet_v1", 9, None), ("mobilenet_v1", 3, True), ("mobilenet_v2", 3, True)])
 def test_dwpw_fusion_equals_the_oracle_graph(lite, wl, plref, which, batch, mode):
     """Depthwise -> pointwise fusion through the predictor and the kernel class (GraphBuilder fusion D; HipConvFusion::pw_*,
-    lite/kernels/hip/conv_fusion.h).  mode None = the DEFAULT lowering: the pairs the fused kernels take (eleven of MobileNetV1's
-    thirteen: all but the two that end on 7 x 7 planes) are ONE launch of plhip_dwpw_fused_int8 each; mode True = every eligible pair is one
+    lite/kernels/hip/conv_fusion.h).  mode None = the DEFAULT lowering: the pairs the fused kernels take (all thirteen of MobileNetV1 at
+    224 x 224) are ONE launch of plhip_dwpw_fused_int8 each; mode True = every eligible pair is one
     instruction, the shapes outside the kernel as two launches inside it.  Every variable the program still produces equals
     the oracle's: int8 bit for bit, fp32 within 1e-5."""
     net = wl.mobilenet_v1_net() if which == "mobilenet_v1" else wl.mobilenet_v2_net()
@@ -436,12 +436,12 @@ def test_dwpw_fusion_equals_the_oracle_graph(lite, wl, plref, which, batch, mode
     try:
         plan = p.graph_plan()
         fused_lines = [l for l in plan if "+pw=" in l]
-        assert len(fused_lines) == ((13 if mode else 11) if which == "mobilenet_v1" else 2)
+        assert len(fused_lines) == (13 if which == "mobilenet_v1" else 2)
         names = p.kernel_names()
         n_one_launch = sum("conv_depthwise_3x3_pointwise_1x1_fused" in n for n in names)
         n_two = sum("conv_depthwise_int8_hip+conv1x1s1" in n for n in names)
         assert n_one_launch + n_two == len(fused_lines), names
-        assert n_one_launch == (11 if which == "mobilenet_v1" else 0), names
+        assert n_one_launch == (13 if which == "mobilenet_v1" else 0), names
         gone = {l.split(" via=")[1].split(" ")[0] for l in fused_lines}
         n_i8 = 0
         for l in plan:

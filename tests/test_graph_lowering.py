@@ -31,16 +31,20 @@ def _plan(lite, wl, net, batch=2, fuse=False, fuse_dwpw=False):
 def test_default_dwpw_fusion_takes_the_pairs_the_fused_kernel_takes(lite, wl):
     """Default lowering (GraphBuilder fusion D, mode 2): the shapes are propagated from the feed and a depthwise conv takes
     its 1x1 consumer over only where plhip_dwpw_fused_supported says the fused kernel runs the pair as ONE launch:
-    eleven of MobileNetV1's thirteen pairs (32 -> 64 @112, 128 -> 128 @56, 256 -> 256 @28 and the stride-2 pairs 64 -> 128 @112 -> 56,
-    128 -> 256 @56 -> 28, 256 -> 512 @28 -> 14 on the streaming kernel, the five 512 -> 512 @14 on the resident-image kernel), at any batch; MobileNetV2
-    has no such pair."""
+    all thirteen pairs of MobileNetV1 at 224 x 224 (32 -> 64 @112, 128 -> 128 @56, 256 -> 256 @28 and the stride-2 pairs 64 -> 128
+    @112 -> 56, 128 -> 256 @56 -> 28, 256 -> 512 @28 -> 14 on the streaming kernel, the five 512 -> 512 @14 on the resident-image
+    kernel, the two that end on 7 x 7 on the small-plane kernel), at any batch; at 192 x 192 no plane has a kernel and the program
+    keeps its 26 conv instructions; MobileNetV2 has no such pair."""
     net = wl.mobilenet_v1_net()
     for batch in (1, 128):
         off, dflt = _plan(lite, wl, net, batch=batch, fuse=True, fuse_dwpw=False), _plan(lite, wl, net, batch=batch, fuse=True, fuse_dwpw=None)
         fl = [l for l in dflt if "+pw=" in l]
-        assert len(dflt) == len(off) - 11 and len(fl) == 11
-        assert [l.split(" out=")[1].split(" ")[0] for l in fl] == ["pw%d" % i for i in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)]
-        assert [l.split(" via=")[1].split(" ")[0] for l in fl] == ["dw%d" % i for i in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)]
+        assert len(dflt) == len(off) - 13 and len(fl) == 13
+        assert [l.split(" out=")[1].split(" ")[0] for l in fl] == ["pw%d" % i for i in range(2, 15)]
+        assert [l.split(" via=")[1].split(" ")[0] for l in fl] == ["dw%d" % i for i in range(2, 15)]
+    n192 = wl.mobilenet_v1_net(res=192)
+    assert not any("+pw=" in l for l in _plan(lite, wl, n192, fuse=True, fuse_dwpw=None))
+    assert len([l for l in _plan(lite, wl, n192, fuse=True, fuse_dwpw=True) if "+pw=" in l]) == 13
     v2 = wl.mobilenet_v2_net(res=64)
     assert not any("+pw=" in l for l in _plan(lite, wl, v2, fuse=True, fuse_dwpw=None))
     # the reference program (no kHIP fusion) is untouched by the default

@@ -152,7 +152,8 @@ def test_fused_dwpw_support_query_is_host_only(pkg):
     """plhip_dwpw_fused_supported is a pure function of the descriptors (no device): the fused kernel takes the 14 x 14
     stride-1 pairs with 128 | C <= 512 and M = 256 / 512 (MobileNetV1's five 512 -> 512 pairs) and, on its streaming kernel,
     the 112 / 56 / 28-wide stride-1 pairs 32 -> 64, 128 -> 128, 256 -> 256 and the stride-2 pairs 112 -> 56 (64 -> 128),
-    56 -> 28 (128 -> 256) and 28 -> 14 (256 -> 512), every output kind; other planes, strides, filters, channel counts are refused (the predictor then
+    56 -> 28 (128 -> 256) and 28 -> 14 (256 -> 512) and, on the small-plane kernel, the two pairs that end on 7 x 7 (512 -> 1024
+    stride 2, 1024 -> 1024), every output kind; other planes, strides, filters, channel counts are refused (the predictor then
     runs the two kernels)."""
     capi = pkg.capi
     lib = capi.load()
@@ -168,10 +169,12 @@ def test_fused_dwpw_support_query_is_host_only(pkg):
     for (c, hw, m) in [(32, 112, 64), (128, 56, 128), (256, 28, 256)]:
         for out in (capi.OUT_I8, capi.OUT_F32, capi.OUT_I32):
             assert q(128, c, hw, 1, m, out=out) == 1 and q(1, c, hw, 1, m, out=out) == 1, (c, hw, m, out)
-    for (c, hw, m) in [(1024, 7, 1024), (64, 112, 128), (32, 112, 32), (128, 28, 128), (256, 56, 256)]:
+    for out in (capi.OUT_I8, capi.OUT_F32, capi.OUT_I32):  # the 7 x 7 planes
+        assert q(128, 1024, 7, 1, 1024, out=out) == 1 and q(1, 512, 14, 2, 1024, out=out) == 1, out
+    for (c, hw, m) in [(512, 7, 1024), (1024, 7, 512), (64, 112, 128), (32, 112, 32), (128, 28, 128), (256, 56, 256)]:
         assert q(128, c, hw, 1, m) == 0, (c, hw, m)
     for out in (capi.OUT_I8, capi.OUT_F32, capi.OUT_I32):  # stride 2: dw3 / pw3, dw5 / pw5
         assert q(128, 64, 112, 2, 128, out=out) == 1 and q(1, 128, 56, 2, 256, out=out) == 1 and q(7, 256, 28, 2, 512, out=out) == 1, out
     assert q(128, 64, 112, 2, 64) == 0 and q(128, 128, 56, 2, 128) == 0 and q(128, 256, 28, 2, 256) == 0 and q(8, 64, 56, 2, 128) == 0
-    assert q(128, 512, 14, 2, 1024) == 0 and q(128, 512, 14, 1, 1024) == 0 and q(128, 192, 14, 1, 256) == 0 and q(128, 640, 14, 1, 512) == 0
+    assert q(128, 512, 14, 2, 512) == 0 and q(128, 512, 14, 1, 1024) == 0 and q(128, 192, 14, 1, 256) == 0 and q(128, 640, 14, 1, 512) == 0
     assert q(128, 512, 14, 1, 512, k=5) == 0 and q(128, 512, 14, 1, 512, dil=2) == 0 and q(128, 512, 14, 1, 512, groups=1) == 0
