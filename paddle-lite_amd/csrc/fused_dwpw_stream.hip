@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
   // parity; k half h -> kg {2h, 2h + 1}
   const uint32_t trb = (uint32_t)(((h * 2) * 8 + ((lane & 15) >> 1)) * FS_PITCH + ((lane >> 4) & 1) * 16 + (lane & 1) * 8 + n0 * 32);
   const uint32_t wlane = (uint32_t)lane * 16;
-  v4i Wf[2][MW];
+  // weight fragments WD - 1 K-steps ahead (from L2: ~1 us each; two slots where the accumulators leave no registers)
+  constexpr int WD = KS < 4 || NW * MW * 16 >= 200 ? 2 : 4;
+  v4i Wf[WD][MW];
   float psc[2][MW], pbi[2][MW];  // [pass parity]
   auto pass_w = [&](int mp) { return reinterpret_cast<const uint8_t*>(g.wp) + (size_t)((mp * MSPLIT + ms) * MW) * KS * 1024; };  // [mt][ks][64 lanes][16 B]
   auto pass_operands = [&](auto mp_c) __attribute__((always_inline)) {
@@ -264,7 +266,9 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
     const uint8_t* const wpk = pass_w(mp);
     const int mt0 = (mp * MSPLIT + ms) * MW;
 #pragma unroll
-    for (int m = 0; m < MW; ++m) Wf[0][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS) * 1024 + wlane);
+    for (int u = 0; u < WD - 1 && u < KS; ++u)
+#pragma unroll
+      for (int m = 0; m < MW; ++m) Wf[u][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS + u) * 1024 + wlane);
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
       psc[mp & 1][m] = 1.f;
@@ -318,9 +322,10 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
           for (int r = 0; r < 16; ++r) acc[n][m][r] = 0;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
+        if (ks + WD - 1 < KS) {
 #pragma unroll
-          for (int m = 0; m < MW; ++m) Wf[(ks + 1) & 1][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS + ks + 1) * 1024 + wlane);
+          for (int m = 0; m < MW; ++m)
+            Wf[(ks + WD - 1) % WD][m] = *reinterpret_cast<const v4i*>(wpk + ((size_t)m * KS + ks + WD - 1) * 1024 + wlane);
         }
         const uint32_t ka = trb + (uint32_t)ks * (32 * FS_PITCH);
 #pragma unroll
@@ -330,13 +335,12 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
             const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i_ptr_t)(fs_lds + ka + n * 32 + 8 * FS_PITCH));
             const v4i av = {lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
-            for (int m = 0; m < MW; ++m) acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, Wf[ks & 1][m], acc[n][m], 0, 0, 0);
+            for (int m = 0; m < MW; ++m) acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, Wf[ks % WD][m], acc[n][m], 0, 0, 0);
           }
         }
       }
       if constexpr (mp == MP - 1) PLHIP_FS_STAMP(5);
-      // the next pass's first operands arrive under this pass's epilogue (KS even: Wf[0] is free by now)
-      static_assert(MP == 1 || KS % 2 == 0, "operand prefetch of the next pass");
+      // the next pass's first operands arrive under this pass's epilogue (every slot of the ring is free by now)
       if constexpr (mp + 1 < MP) pass_operands(integral_constant<int, mp + 1>{});
       // ---------------------------------------------------------------- epilogue
       // accumulator register r of n tile n: slot 32 (n0 + n) + 8 (r >> 2) + 4 h + (r & 3); lane (c, h) owns channel 32 (mt0 + m) + c

@@ -223,12 +223,12 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
       bool pad0 = true;
       for (int v : c.conv.paddings) pad0 = pad0 && v == 0;
       if (!pad0 || !st[j].res.empty() || !st[j].calib_out.empty() || st[j].drop_f32) continue;
+      plhip_conv_desc d;
+      memset(&d, 0, sizeof(d));
       if (fuse_dwpw_ == 2) {
         const GraphOp& dwo = ops_[st[i].op];
         auto it = st[i].op_inputs.empty() ? shape.end() : shape.find(st[i].op_inputs[0]);
         if (it == shape.end() || it->second.size() != 4 || dwo.conv.paddings.size() != 4) continue;
-        plhip_conv_desc d;
-        memset(&d, 0, sizeof(d));
         d.n = static_cast<int>(it->second[0]); d.cin = static_cast<int>(it->second[1]);
         d.h = static_cast<int>(it->second[2]); d.w = static_cast<int>(it->second[3]);
         d.cout = static_cast<int>(dwo.w_dims[0]); d.kh = static_cast<int>(dwo.w_dims[2]); d.kw = static_cast<int>(dwo.w_dims[3]);
@@ -244,6 +244,23 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
       st[i].via = st[i].out;
       st[i].out = st[j].out;
       dead[j] = true;
+      // (E) ... and the global average pool2d that is the only reader of that conv's fp32 output, where the fused kernel writes
+      // the plane average itself (PLHIP_OUT_F32_GAP): MobileNetV1's pw14 -> pool
+      if (fuse_dwpw_ == 2 && !st[i].pw_int8_out && uses(st[i].out) == 1) {
+        int pj = -1;
+        for (size_t t = 0; t < st.size(); ++t)
+          if (!dead[t] && st[t].kind == "op" && !st[t].op_inputs.empty() && st[t].op_inputs[0] == st[i].out) pj = static_cast<int>(t);
+        if (pj >= 0) {
+          const GraphOp& po = ops_[st[pj].op];
+          if (po.type == "pool2d" && po.pooling_type == "avg" && po.global_pooling && !st[pj].pool_int8 &&
+              plhip_dwpw_fused_supported(&d, static_cast<int>(c.w_dims[0]), PLHIP_OUT_F32_GAP)) {
+            st[i].pw_pool = true;
+            st[i].via_pw = st[i].out;
+            st[i].out = st[pj].out;
+            dead[pj] = true;
+          }
+        }
+      }
     }
   }
   std::vector<Step> kept;
@@ -288,6 +305,7 @@ std::vector<std::string> GraphBuilder::Plan() {
           snprintf(buf, sizeof buf, " pw_oscale=%.9g", s.pw_out_scale);
           l += buf;
         }
+        if (s.pw_pool) l += " +pool=avg/global pw_out=" + s.via_pw;
       }
     } else {
       l = s.kind == "io_copy_h2d" ? "io_copy/host_to_device"
@@ -339,6 +357,7 @@ std::vector<std::string> GraphBuilder::Lower(HipPredictor* pred) {
           a.pw_int8_out = s.pw_int8_out;
           a.pw_act = c.conv.act;
           a.pw_act_coef = c.conv.act_coef;
+          a.pw_pool = s.pw_pool;
         }
         pred->AddConv(op.type, s.op_inputs[0], s.out, op.w.data(), op.w_dims, op.has_bias ? op.bias.data() : nullptr, a);
       } else if (op.type == "fc") {

@@ -87,6 +87,8 @@ class GraphBuilder {
     bool pw_int8_out{true};
     float pw_out_scale{1.f};
     std::string via;          // name the depthwise result would have had
+    bool pw_pool{false};      // ... and that conv's sole consumer, a global average pool2d, too (E): `out` is the pool's output
+    std::string via_pw;       // name the 1x1 conv's result would have had
   };
   std::vector<Step> Schedule();
   void FuseSteps(std::vector<Step>* steps);

@@ -131,6 +131,11 @@ void HipPredictor::AddConv(const std::string& op_type, const std::string& in, co
       if (a.pw_act == 4) fz.pw_activation_param.Leaky_relu_alpha = a.pw_act_coef;
     }
     p.output->set_precision(a.pw_int8_out ? PRECISION(kInt8) : PRECISION(kFloat));
+    if (a.pw_pool) {
+      CHECK(!a.pw_int8_out) << "the fused global average pool reads the 1x1 conv's fp32 output";
+      fz.pw_global_avg_pool = true;
+      op->set_output_pooled();
+    }
   }
   op->set_padding_algorithm(a.padding_algorithm);
   auto kernel = PickKernel(op_type, Place(TARGET(kHIP), PRECISION(kInt8)), a.int8_out ? "int8_out" : "fp32_out");

@@ -44,6 +44,7 @@ struct ConvAttrs {
   bool pw_int8_out{true};
   int pw_act{0};
   float pw_act_coef{0.f};
+  bool pw_pool{false};  // ... and the global average pool2d behind it: `out` is the pool's output, [n, cout, 1, 1] fp32
 };
 
 class HipPredictor {

@@ -61,6 +61,7 @@ class ConvOpLite : public OpLite {
   ConvParam& mutable_param() { return param_; }
   void set_padding_algorithm(const std::string& a) { padding_algorithm_ = a; }
   void set_output_channels(int64_t c) { out_channels_override_ = c; }  // kHIP fusions only (lite/kernels/hip/conv_fusion.h)
+  void set_output_pooled() { out_pooled_ = true; }                     // ... with the global average pool behind it: [n, c, 1, 1]
   bool CheckShape() const override {
     CHECK(param_.x && param_.filter && param_.output) << "conv: x / filter / output must be set";
     const auto in = param_.x->dims(), f = param_.filter->dims();
@@ -85,6 +86,8 @@ class ConvOpLite : public OpLite {
     for (size_t i = 0; i < param_.strides.size(); ++i)
       out.push_back(ConvOutputSize(static_cast<int>(in[i + 2]), static_cast<int>(f[i + 2]), (*param_.dilations)[i],
                                    (*param_.paddings)[i * 2], (*param_.paddings)[i * 2 + 1], param_.strides[i]));
+    if (out_pooled_)
+      for (size_t i = 2; i < out.size(); ++i) out[i] = 1;
     param_.output->Resize(out);
     return true;
   }
@@ -94,6 +97,7 @@ class ConvOpLite : public OpLite {
   mutable ConvParam param_;
   std::string padding_algorithm_{""};
   int64_t out_channels_override_{0};
+  bool out_pooled_{false};
 };
 
 class FcOpLite : public OpLite {

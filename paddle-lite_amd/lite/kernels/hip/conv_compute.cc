@@ -99,13 +99,14 @@ void ConvCompute<Ptype, OutType>::ReInitWhenNeeded() {
     }
   }
   workspace_bytes_ = is_depthwise_ ? 0 : plhip_conv_workspace_bytes(&desc_);
-  if (has_pw_) {  // the pointwise conv sees the depthwise conv's output plane
-    const auto od = param.output->dims();
+  if (has_pw_) {  // the pointwise conv sees the depthwise conv's output plane (`output` may be the pooled one: from the descriptor)
     pw_desc_.n = desc_.n;
-    pw_desc_.h = static_cast<int>(od[2]);
-    pw_desc_.w = static_cast<int>(od[3]);
-    pw_fused_ = plhip_dwpw_fused_supported(&desc_, pw_desc_.cout, fusion_.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32) != 0;
+    pw_desc_.h = (desc_.h + desc_.pad[0] + desc_.pad[1] - (desc_.dil[0] * (desc_.kh - 1) + 1)) / desc_.stride[0] + 1;
+    pw_desc_.w = (desc_.w + desc_.pad[2] + desc_.pad[3] - (desc_.dil[1] * (desc_.kw - 1) + 1)) / desc_.stride[1] + 1;
+    const bool gap = fusion_.pw_global_avg_pool;
+    pw_fused_ = plhip_dwpw_fused_supported(&desc_, pw_desc_.cout, gap ? PLHIP_OUT_F32_GAP : (fusion_.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32)) != 0;
     kernel_func_name_ = pw_fused_ ? "conv_depthwise_3x3_pointwise_1x1_fused_int8_hip" : "conv_depthwise_int8_hip+conv1x1s1_gemm_int8_mfma32x32x32";
+    if (gap) kernel_func_name_ += "+pooling_global_avg";
   }
   last_shape_ = param.x->dims();
 }
@@ -280,17 +281,25 @@ void ConvCompute<Ptype, OutType>::Run() {
     // `output` is the pointwise conv's tensor (HipConvFusion::pw_*); y above was allocated as int8: redo it for fp32
     void* yo = fusion_.pw_int8_out ? static_cast<void*>(param.output->template mutable_data<int8_t>(TARGET(kHIP)))
                                  : static_cast<void*>(param.output->template mutable_data<float>(TARGET(kHIP)));
-    const plhip_out_kind ko = fusion_.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32;
+    const bool gap = fusion_.pw_global_avg_pool;  // `output` is the pool's [n, cout, 1, 1]
+    const plhip_out_kind ko = gap ? PLHIP_OUT_F32_GAP : (fusion_.pw_int8_out ? PLHIP_OUT_I8 : PLHIP_OUT_F32);
     const float* psc = pw_scale_.data<float>();
     const float* pbi = pw_has_bias_ ? pw_bias_.data<float>() : nullptr;
     if (pw_fused_) {
       HIP_CALL(ctx.ctx(), plhip_dwpw_fused_int8(ctx.ctx(), &desc_, x, weights_.data<int8_t>(), sc, bi, pw_desc_.cout,
                                                 pw_weights_.raw_data(), psc, pbi, pw_desc_.act, pw_desc_.act_alpha, yo, ko));
-    } else {  // shape outside the fused kernel: the two kernels, the depthwise result in a private tensor
+    } else {  // shape outside the fused kernel: the kernels one by one, the intermediate results in private tensors
       mid_.Resize({desc_.n, desc_.cout, pw_desc_.h, pw_desc_.w});
       int8_t* mid = mid_.mutable_data<int8_t>(TARGET(kHIP));
       HIP_CALL(ctx.ctx(), plhip_depthwise_conv_int8(ctx.ctx(), &desc_, x, weights_.data<int8_t>(), sc, bi, mid, PLHIP_OUT_I8));
-      HIP_CALL(ctx.ctx(), plhip_conv2d_int8(ctx.ctx(), &pw_desc_, mid, pw_weights_.raw_data(), psc, pbi, yo, ko, nullptr, 0));
+      if (gap) {
+        mid2_.Resize({desc_.n, pw_desc_.cout, pw_desc_.h, pw_desc_.w});
+        float* m2 = mid2_.mutable_data<float>(TARGET(kHIP));
+        HIP_CALL(ctx.ctx(), plhip_conv2d_int8(ctx.ctx(), &pw_desc_, mid, pw_weights_.raw_data(), psc, pbi, m2, PLHIP_OUT_F32, nullptr, 0));
+        HIP_CALL(ctx.ctx(), plhip_global_avg_pool_f32(ctx.ctx(), m2, desc_.n * pw_desc_.cout, pw_desc_.h * pw_desc_.w, static_cast<float*>(yo)));
+      } else {
+        HIP_CALL(ctx.ctx(), plhip_conv2d_int8(ctx.ctx(), &pw_desc_, mid, pw_weights_.raw_data(), psc, pbi, yo, ko, nullptr, 0));
+      }
     }
   } else if (is_depthwise_) {
     HIP_CALL(ctx.ctx(), plhip_depthwise_conv_int8(ctx.ctx(), &desc_, x, weights_.data<int8_t>(), sc, bi, y, kind));

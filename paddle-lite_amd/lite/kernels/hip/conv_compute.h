@@ -49,7 +49,7 @@ class ConvCompute : public KernelLite<TARGET(kHIP), Ptype>, public HipFusableKer
   void PreparePointwise();
   bool has_pw_{false}, pw_fused_{false}, pw_has_bias_{false};
   plhip_conv_desc pw_desc_{};
-  Tensor pw_weights_, pw_scale_, pw_bias_, mid_;
+  Tensor pw_weights_, pw_scale_, pw_bias_, mid_, mid2_;
 };
 
 }  // namespace hip

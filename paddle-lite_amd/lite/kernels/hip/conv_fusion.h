@@ -40,6 +40,10 @@ struct HipConvFusion {
   float pw_output_scale{1.f};
   bool pw_int8_out{true};
   operators::ActivationParam pw_activation_param;
+  // ... and that conv's sole consumer, pool2d(avg, global_pooling) (graph_builder.cc, fusion E): `output` is then the POOL's
+  // output [n, cout, 1, 1]; the fused kernel writes the plane average itself (PLHIP_OUT_F32_GAP), other shapes run the
+  // instructions one by one inside the kernel object
+  bool pw_global_avg_pool{false};
 };
 
 class HipFusableKernel {

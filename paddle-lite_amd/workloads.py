@@ -356,10 +356,11 @@ def program_costs(net, batch, plan_lines):
             byts = sum(numel(i) * esz[i] for i in ins) + wbytes
             if "+pw" in kv:       # opt-in fusion: this depthwise conv took its 1x1 consumer over: `dst` is that conv's output
                 o2 = next(int8_ops)
-                assert o2["op"] == "conv2d" and o2["name"] == dst, (o2["name"], line)
+                pw_name = kv.get("pw_out", dst)  # (+pool: `dst` is the global average pool's output, the conv's plane is never written)
+                assert o2["op"] == "conv2d" and o2["name"] == pw_name, (o2["name"], line)
                 esz[dst] = 1 if kv["+pw"].endswith("int8_out") else 4
                 m2, c2 = o2["w"].shape[0], o2["w"].shape[1]
-                _, h2, w2 = shapes[dst]
+                _, h2, w2 = shapes[pw_name]
                 macs += batch * h2 * w2 * m2 * c2
                 wbytes += int(o2["w"].size)
                 byts += int(o2["w"].size)

@@ -50,10 +50,26 @@ timeout -k 10 100 python tools/fused_timeline.py > $O/fused_timeline_b128.txt 2>
 timeout -k 10 100 python tools/fused_timeline.py --batch 256 > $O/fused_timeline_b256.txt 2>&1 || exit 1
 for e in 1 2 3 19 4; do timeout -k 10 100 python tools/fused_timeline.py --exp $e > $O/fused_timeline_exp$e.txt 2>&1 || exit 1; done
 for cfg in "128 128 56" "32 64 112" "256 256 28"; do set -- $cfg; timeout -k 10 100 python tools/stream_timeline.py --c $1 --m $2 --hw $3 > $O/stream_timeline_$3.txt 2>&1 || exit 1; done
+# ... its stride-2 forms and the small-plane kernel (the 7 x 7 pairs; one / two blocks per image; the pooled output), and every pair
+# fused against the two kernels (wall clock over 50 launches)
+for cfg in "64 128 112" "128 256 56" "256 512 28"; do set -- $cfg; timeout -k 10 100 python tools/stream_timeline.py --c $1 --m $2 --hw $3 --stride 2 > $O/stream_timeline_$3_s2.txt 2>&1 || exit 1; done
+timeout -k 10 100 python tools/stream_timeline.py --c 512 --m 1024 --hw 14 --stride 2 > $O/small_timeline_14_s2.txt 2>&1 || exit 1
+timeout -k 10 100 python tools/stream_timeline.py --c 1024 --m 1024 --hw 7 --f32 > $O/small_timeline_7_f32.txt 2>&1 || exit 1
+PLHIP_FUSED_SMALL=2 timeout -k 10 100 python tools/stream_timeline.py --c 1024 --m 1024 --hw 7 --f32 > $O/small_timeline_7_f32_two_blocks.txt 2>&1 || exit 1
+: > $O/fused_vs_two_kernels.txt
+for cfg in "32 64 112 1" "64 128 112 2" "128 128 56 1" "128 256 56 2" "256 256 28 1" "256 512 28 2" "512 512 14 1" "512 1024 14 2" "1024 1024 7 1"; do set -- $cfg
+  echo "dw3x3 s$4 + pw1x1 $1 -> $2 @$3:" >> $O/fused_vs_two_kernels.txt
+  timeout -k 10 120 python tools/fused_run.py --c $1 --m $2 --hw $3 --stride $4 --two --reps 50 2>&1 | grep "us per" >> $O/fused_vs_two_kernels.txt || exit 1
+done
+PLHIP_FUSED_SMALL=2 timeout -k 10 200 python tools/opbench.py fused 2>&1 | cut -c1-110 | grep "fused\|2-krn" > $O/opbench_fused_small_two_blocks.txt || exit 1
 [ -x tools/_probe_coexec ] && ./tools/_probe_coexec > $O/probe_coexec.txt 2>&1
 [ -x tools/_probe_rtz ] && ./tools/_probe_rtz > $O/probe_cvt_rtz.txt 2>&1
-PLHIP_FUSED_STREAM=0 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_stream_off.json 2>/dev/null || exit 1
-PLHIP_FUSED_STREAM=0 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_stream_off_inflight1.json 2>/dev/null || exit 1
+PLHIP_FUSED_STREAM=0 PLHIP_FUSED_SMALL=0 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_stream_off.json 2>/dev/null || exit 1
+PLHIP_FUSED_STREAM=0 PLHIP_FUSED_SMALL=0 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_stream_off_inflight1.json 2>/dev/null || exit 1
+PLHIP_FUSED_STREAM=2 PLHIP_FUSED_SMALL=0 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_stride1_only.json 2>/dev/null || exit 1
+PLHIP_FUSED_SMALL=0 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_small_off.json 2>/dev/null || exit 1
+PLHIP_FUSED_SMALL=2 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_small_two_blocks.json 2>/dev/null || exit 1
+PLHIP_BENCH_FUSE_DWPW=1 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_no_pool_tail.json 2>/dev/null || exit 1
 PLHIP_BENCH_FUSE_DWPW=0 timeout -k 10 200 python bench.py --no-cpu-baseline > $O/bench_dwpw_off.json 2>/dev/null || exit 1
 PLHIP_BENCH_FUSE_DWPW=0 timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 > $O/bench_dwpw_off_inflight1.json 2>/dev/null || exit 1
 timeout -k 10 200 python tools/opbench.py all --batch 256 2>&1 | cut -c1-110 | grep -v "fused\|2-krn" > $O/opbench_b256.txt || exit 1

@@ -36,7 +36,10 @@ for f in ("bench_c4.json", "bench_c5.json", "bench_c2.json", "bench_force_dist.j
           "opbench_fused.txt", "fused_timeline_b128.txt", "fused_timeline_b256.txt", "fused_timeline_exp1.txt", "fused_timeline_exp2.txt",
           "fused_timeline_exp3.txt", "fused_timeline_exp19.txt", "fused_timeline_exp4.txt", "probe_coexec.txt", "probe_cvt_rtz.txt",
           "bench_dwpw_off.json", "bench_dwpw_off_inflight1.json", "bench_stream_off.json", "bench_stream_off_inflight1.json",
-          "stream_timeline_56.txt", "stream_timeline_112.txt", "stream_timeline_28.txt"):
+          "stream_timeline_56.txt", "stream_timeline_112.txt", "stream_timeline_28.txt", "stream_timeline_112_s2.txt",
+          "stream_timeline_56_s2.txt", "stream_timeline_28_s2.txt", "small_timeline_14_s2.txt", "small_timeline_7_f32.txt",
+          "small_timeline_7_f32_two_blocks.txt", "fused_vs_two_kernels.txt", "opbench_fused_small_two_blocks.txt", "bench_stride1_only.json",
+          "bench_small_off.json", "bench_small_two_blocks.json", "bench_no_pool_tail.json"):
     if os.path.exists(os.path.join(E, f)):
         cp(f, f)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
