@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
   const uint32_t trb = (uint32_t)(((h * 2) * 8 + ((lane & 15) >> 1)) * FS_PITCH + ((lane >> 4) & 1) * 16 + (lane & 1) * 8 + n0 * 32);
   const uint32_t wlane = (uint32_t)lane * 16;
   // weight fragments WD - 1 K-steps ahead (from L2: ~1 us each; two slots where the accumulators leave no registers)
-  constexpr int WD = KS < 4 || NW * MW * 16 >= 200 ? 2 : 4;
+  constexpr int WD = KS < 4 || NW * MW * 16 > 112 ? 2 : 4;
   v4i Wf[WD][MW];
   float psc[2][MW], pbi[2][MW];  // [pass parity]
   auto pass_w = [&](int mp) { return reinterpret_cast<const uint8_t*>(g.wp) + (size_t)((mp * MSPLIT + ms) * MW) * KS * 1024; };  // [mt][ks][64 lanes][16 B]
@@ -450,7 +450,9 @@ static void launch_stream_t(FusedArgs a, hipStream_t s) {
   a.pw.NT = (a.oh + TR - 1) / TR;  // tiles per image
   a.tiles = a.n * a.pw.NT;
   const unsigned blocks = (unsigned)((a.tiles + 7) / 8 * 8);
-  const size_t lds = (size_t)K * fs_pitch(TP) + (size_t)K * 32 + 512;  // image, depthwise parameters, sink of the idle lanes
+  // image, depthwise parameters, sink of the idle lanes (256 -> 256 @28 has none: its 80 KiB are exactly half a CU's LDS, and
+  // 512 bytes more made it one block per CU: 28.3 -> 34.0 us)
+  const size_t lds = (size_t)K * fs_pitch(TP) + (size_t)K * 32 + (M / MP < 256 ? 512 : 0);
   const bool dwnn = a.dw_act == ACT_RELU || a.dw_act == ACT_RELU6;
   const bool pwnn = OUT == OUT_I8 && (a.pw.act == ACT_RELU || a.pw.act == ACT_RELU6);
 #define PLHIP_FS_LAUNCH(DN, PN)                                                                                  \
