@@ -460,7 +460,13 @@ def main():
         if use_dist:
             local = [torch.zeros((max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
             gathered = [torch.empty((world * max_rows, classes), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
-            slot_free = [threading.Semaphore(1) for _ in range(DEPTH)]
+            # a slot is handed on in STEP ORDER: step g may stage into slot g % DEPTH once the collective of step g - DEPTH has been
+            # issued (`issued` = number of steps whose collective the coordinator has issued, all windows).  A free-for-all
+            # semaphore per slot deadlocked: predictor 0, three steps ahead of a predictor that was still asleep in its start
+            # offset, took the slot of that predictor's first step, and the coordinator, which issues in step order, waited for
+            # that first step for ever (round 4: the N > 1 path hung twice in the evidence script, never stand-alone)
+            issued = [0]
+            issued_cv = threading.Condition()
             slot_event = [None] * DEPTH
             pending = [None] * DEPTH
         coord_stream = None if dry else torch.cuda.Stream(dev)
@@ -496,8 +502,11 @@ def main():
                         for s_ in range(self.i, self.n, P):
                             e.run()
                             if use_dist:
-                                b = (self.base + s_) % DEPTH
-                                slot_free[b].acquire()      # host: the collective that last read this slot has been ISSUED
+                                gstep = self.base + s_
+                                b = gstep % DEPTH
+                                with issued_cv:              # host: the collective that last read this slot (step g - DEPTH) has been ISSUED
+                                    while issued[0] < gstep - DEPTH + 1 and self.alive:
+                                        issued_cv.wait(1.0)
                                 e.wait_event(slot_event[b])  # device: ... and will have FINISHED before the copy below
                                 e.stage(local[b], out_bytes)
                                 self.doneq.put(e.record())
@@ -543,7 +552,9 @@ def main():
                             fe.record(coord_stream)
                         slot_event[b] = fe
                     last_gather[0] = gathered[b]
-                    slot_free[b].release()
+                    with issued_cv:
+                        issued[0] = step_base[0] + s_ + 1
+                        issued_cv.notify_all()
             for f_ in flights:
                 f_.done.acquire()
                 if f_.err:

@@ -130,6 +130,17 @@ plhip_status plhip_conv2d_int8_fused(plhip_ctx* ctx, const plhip_conv_desc* d, c
                                      int residual_relu, int8_t* y_i8, float calib_scale, void* workspace,
                                      size_t workspace_bytes);
 
+/* ---- calib[fp32_to_int8] + conv2d in one launch (graph-level fusion on this target) ----
+ * Replaces the instruction pair  calib[fp32_to_int8](scale) ; conv2d 3x3 s2 (Cin <= 3)  at the head of the MobileNet programs
+ * (lite/kernels/arm/calib_compute.cc:25-40 -> type_trans.cc:34-187 ; lite/kernels/arm/conv_direct.cc): x_f32 is the calib's
+ * fp32 input [n, cin, h, w], calib_scale its scale; every value is quantised exactly as plhip_calib_f32_to_i8 does and
+ * convolved exactly as plhip_conv2d_int8 does: bit-identical to the two calls, the int8 image never exists.  w_packed: what
+ * plhip_pack_conv_weights made for `d`.  plhip_conv2d_calib_supported: 1 where the fused kernel takes the conv (3x3 stride 2,
+ * cin <= 3, left padding 1, top padding <= 1, w % 4 == 0, ow % 4 == 0), else the caller runs the two instructions. */
+int plhip_conv2d_calib_supported(const plhip_conv_desc* d);
+plhip_status plhip_conv2d_calib_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const float* x_f32, float calib_scale,
+                                     const void* w_packed, const float* scale, const float* bias, void* y, plhip_out_kind out);
+
 /* ---- depthwise conv (groups == cin == cout) ----
  * Replaces: DepthwiseConv<kInt8,*>::Run (lite/kernels/arm/conv_depthwise.cc:357-446) ->
  * conv_depthwise_3x3_int8_{fp32,int8} / conv_depthwise_5x5_int8_{fp32,int8}

@@ -27,7 +27,7 @@ EXPORTS = [
     "plhip_fc_packed_weight_bytes", "plhip_pack_fc_weights", "plhip_fc_int8",
     "plhip_calib_f32_to_i8", "plhip_calib_i8_to_f32", "plhip_global_avg_pool_f32", "plhip_softmax_f32",
     "plhip_pool2d_f32", "plhip_pool2d_max_i8", "plhip_elementwise_add_f32", "plhip_selftest",
-    "plhip_debug_set", "plhip_debug_read_fw_stamps", "plhip_debug_read_fs_stamps", "plhip_debug_read_f7_stamps",
+    "plhip_debug_set", "plhip_debug_read_fw_stamps", "plhip_debug_read_fs_stamps", "plhip_debug_read_f7_stamps", "plhip_conv2d_calib_supported", "plhip_conv2d_calib_int8",
 ]
 
 
@@ -125,6 +125,8 @@ def load():
     L.plhip_conv_workspace_bytes.restype = sz
     L.plhip_conv2d_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp, sz]
     L.plhip_conv2d_int8_fused.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i32, vp, f32, vp, sz]
+    L.plhip_conv2d_calib_supported.argtypes = [C.POINTER(ConvDesc)]
+    L.plhip_conv2d_calib_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, f32, vp, vp, vp, vp, i32]
     L.plhip_conv_impl_name.argtypes = [C.POINTER(ConvDesc)]
     L.plhip_conv_impl_name.restype = C.c_char_p
     L.plhip_depthwise_conv_int8.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32]
@@ -231,6 +233,22 @@ class Context:
             tmp += [dwp] + ([dws] if wsb else [])
         y = self.to_host(dy, (d.n, d.cout, oh, ow), _OUT_DTYPE[out_kind])
         for p in tmp + ([ds] if scale is not None else []) + ([db] if bias is not None else []):
+            self.free(p)
+        return y
+
+    def conv2d_calib(self, d, x_f32, calib_scale, w, scale, bias, out_kind):
+        """plhip_conv2d_calib_int8 on host arrays: calib[fp32_to_int8](calib_scale) + conv2d in one launch."""
+        oh, ow = out_hw(d)
+        dx = self.to_device(np.ascontiguousarray(x_f32, np.float32))
+        dw = self.to_device(np.ascontiguousarray(w, np.int8))
+        ds = self.to_device(np.ascontiguousarray(scale, np.float32)) if scale is not None else C.c_void_p()
+        db = self.to_device(np.ascontiguousarray(bias, np.float32)) if bias is not None else C.c_void_p()
+        dy = self.malloc(d.n * d.cout * oh * ow * (1 if out_kind == OUT_I8 else 4))
+        dwp = self.malloc(self.L.plhip_conv_packed_weight_bytes(C.byref(d)))
+        self.check(self.L.plhip_pack_conv_weights(self.h, C.byref(d), dw, dwp), "pack")
+        self.check(self.L.plhip_conv2d_calib_int8(self.h, C.byref(d), dx, calib_scale, dwp, ds, db, dy, out_kind), "conv2d_calib")
+        y = self.to_host(dy, (d.n, d.cout, oh, ow), _OUT_DTYPE[out_kind])
+        for p in [dx, dw, dy, dwp] + ([ds] if scale is not None else []) + ([db] if bias is not None else []):
             self.free(p)
         return y
 

@@ -29,6 +29,7 @@ bool conv3x3s2_direct_supported(int cin, int cout, int kh, int kw, int sh, int s
 // packed block = [dot4 layout: cin*3 x coutp dwords][MFMA A fragments: ceil(cout/32) x 1 KiB] — both are always written,
 // the kernel is picked per launch (the MFMA form needs Cin*9 <= 32 and OW % 4 == 0)
 static size_t ds2_dot4_bytes(int cin, int cout) { return (size_t)cin * 3 * ((cout + 3) / 4 * 4) * 4; }
+size_t conv3x3s2_dot4_bytes(int cin, int cout) { return ds2_dot4_bytes(cin, cout); }
 size_t conv3x3s2_direct_packed_bytes(int cin, int cout) { return ds2_dot4_bytes(cin, cout) + (size_t)((cout + 31) / 32) * 1024; }
 
 __global__ void pack_conv3x3s2_direct_kernel(const int8_t* __restrict__ w, uint32_t* __restrict__ wp, int cin, int cout, int coutp) {

@@ -605,6 +605,46 @@ plhip_status plhip_conv2d_int8_fused(plhip_ctx* ctx, const plhip_conv_desc* d, c
   return conv2d_impl(ctx, d, x, w_packed, scale, bias, y_f32, PLHIP_OUT_F32, workspace, workspace_bytes, &t);
 }
 
+// ------------------------------------------------------------------ calib[fp32_to_int8] + conv in one launch
+static bool calib_conv_args(const plhip_conv_desc* d, plhip::DirectS2Args* a) {
+  ConvGeom g;
+  if (!d || !conv_geom(d, &g) || g.impl != IMPL_DIRECT_3X3S2) return false;
+  *a = plhip::DirectS2Args();
+  a->n = d->n; a->cin = d->cin; a->h = d->h; a->w = d->w; a->cout = d->cout; a->coutp = rup(d->cout, 4);
+  a->oh = g.oh; a->ow = g.ow; a->pt = d->pad[0]; a->pl = d->pad[2]; a->act = d->act; a->alpha = d->act_alpha;
+  return plhip::conv3x3s2_f32in_supported(*a);
+}
+
+int plhip_conv2d_calib_supported(const plhip_conv_desc* d) {
+  plhip::DirectS2Args a;
+  return calib_conv_args(d, &a) ? 1 : 0;
+}
+
+plhip_status plhip_conv2d_calib_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const float* x_f32, float calib_scale,
+                                     const void* w_packed, const float* scale, const float* bias, void* y, plhip_out_kind out) {
+  if (!ctx || !x_f32 || !w_packed || !y || !(calib_scale > 0.f)) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_calib_int8: null / bad argument");
+  if (out != PLHIP_OUT_I32_ACC && out != PLHIP_OUT_F32 && out != PLHIP_OUT_I8)
+    return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_calib_int8: bad out kind");
+  if (out != PLHIP_OUT_I32_ACC && !scale) return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_calib_int8: scale required");
+  if (d && d->act != PLHIP_ACT_NONE && d->act != PLHIP_ACT_RELU && d->act != PLHIP_ACT_RELU6 && d->act != PLHIP_ACT_LEAKY_RELU)
+    return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_calib_int8: unsupported activation");
+  plhip::DirectS2Args a;
+  if (!calib_conv_args(d, &a)) return fail(ctx, PLHIP_ERR_UNSUPPORTED, "plhip_conv2d_calib_int8: shape outside the fused stem");
+  const size_t esz = out == PLHIP_OUT_I8 ? 1 : 4;
+  if (!aligned(x_f32, 16) || !aligned(y, 4 * esz) || !aligned(w_packed, 16))
+    return fail(ctx, PLHIP_ERR_INVALID, "plhip_conv2d_calib_int8: x / w_packed must be 16-byte aligned, y 4 elements");
+  a.xf = x_f32;
+  a.x_inv_scale = 1.f / calib_scale;  // type_trans.cc:45
+  a.wp = (const uint32_t*)w_packed;
+  a.y = y;
+  a.scale = scale;
+  a.bias = bias;
+  const int8_t* afrag = reinterpret_cast<const int8_t*>(w_packed) + plhip::conv3x3s2_dot4_bytes(d->cin, d->cout);
+  plhip::launch_conv3x3s2_f32in(a, afrag, (int)out, ctx->stream);
+  LAUNCHCHK(ctx, "conv3x3s2_f32in");
+  return PLHIP_OK;
+}
+
 // ------------------------------------------------------------------ depthwise
 plhip_status plhip_depthwise_conv_int8(plhip_ctx* ctx, const plhip_conv_desc* d, const int8_t* x, const int8_t* w_oihw,
                                        const float* scale, const float* bias, void* y, plhip_out_kind out) {

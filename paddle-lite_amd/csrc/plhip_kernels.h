@@ -209,6 +209,9 @@ struct DirectS2Args {
   int res_relu = 0;
   int8_t* y2 = nullptr;
   float inv_scale2 = 0.f;
+  // fused calib[fp32_to_int8] in front (conv_stem_f32in.hip): the fp32 image and 1 / its quantisation scale
+  const float* xf = nullptr;
+  float x_inv_scale = 0.f;
 };
 // conv_stem7_i8.hip: 7x7 stride 2, Cin <= 3 (ResNet50's stem); wp = its A fragments
 bool conv7x7s2_stem_supported(int cin, int cout, int kh, int kw, int sh, int sw, int dh, int dw, int groups, int n, int h, int w,
@@ -220,6 +223,9 @@ bool conv3x3s2_direct_supported(int cin, int cout, int kh, int kw, int sh, int s
 size_t conv3x3s2_direct_packed_bytes(int cin, int cout);
 void launch_pack_conv3x3s2_direct(const int8_t* w_oihw, uint32_t* wp, int cin, int cout, hipStream_t s);
 void launch_conv3x3s2_direct(const DirectS2Args& a, int out, hipStream_t s);
+size_t conv3x3s2_dot4_bytes(int cin, int cout);              // offset of the MFMA A fragments inside the packed block
+bool conv3x3s2_f32in_supported(const DirectS2Args& a);      // conv_stem_f32in.hip: calib[fp32_to_int8] + this conv in one launch
+void launch_conv3x3s2_f32in(const DirectS2Args& a, const int8_t* afrag, int out, hipStream_t s);
 
 size_t fc_packed_bytes(int k, int n);
 void launch_pack_fc(const int8_t* w_kn, int8_t* wp, int k, int n, hipStream_t s);

@@ -122,6 +122,10 @@ std::vector<GraphBuilder::Step> GraphBuilder::Schedule() {
 void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
   std::vector<Step>& st = *steps_io;
   std::vector<bool> dead(st.size(), false);
+  // conv_op.h:149-161: 2-element paddings mean {top = bottom, left = right}
+  auto pad4 = [](const std::vector<int>& p) {
+    return p.size() == 2 ? std::vector<int>{p[0], p[0], p[1], p[1]} : p;
+  };
   auto uses = [&](const std::string& v) {
     int n = 0;
     for (size_t i = 0; i < st.size(); ++i) {
@@ -191,11 +195,12 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
       if (it == shape.end() || it->second.size() != 4) continue;
       const std::vector<int64_t> in = it->second;
       std::vector<int64_t> o;
-      if ((op.type == "conv2d" || op.type == "depthwise_conv2d") && op.w_dims.size() == 4 && op.conv.paddings.size() == 4 &&
-          op.conv.strides.size() == 2 && op.conv.dilations.size() == 2) {
+      const std::vector<int> pd = pad4(op.conv.paddings);
+      if ((op.type == "conv2d" || op.type == "depthwise_conv2d") && op.w_dims.size() == 4 && pd.size() == 4 &&
+          op.conv.strides.size() == 2 && op.conv.dilations.size() == 2 && op.conv.padding_algorithm.empty()) {
         const int64_t keh = op.conv.dilations[0] * (op.w_dims[2] - 1) + 1, kew = op.conv.dilations[1] * (op.w_dims[3] - 1) + 1;
-        o = {in[0], op.w_dims[0], (in[2] + op.conv.paddings[0] + op.conv.paddings[1] - keh) / op.conv.strides[0] + 1,
-             (in[3] + op.conv.paddings[2] + op.conv.paddings[3] - kew) / op.conv.strides[1] + 1};
+        o = {in[0], op.w_dims[0], (in[2] + pd[0] + pd[1] - keh) / op.conv.strides[0] + 1,
+             (in[3] + pd[2] + pd[3] - kew) / op.conv.strides[1] + 1};
       } else if (op.type == "elementwise_add" || op.type == "fusion_elementwise_add_activation") {
         o = in;
       }
@@ -228,11 +233,12 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
       if (fuse_dwpw_ == 2) {
         const GraphOp& dwo = ops_[st[i].op];
         auto it = st[i].op_inputs.empty() ? shape.end() : shape.find(st[i].op_inputs[0]);
-        if (it == shape.end() || it->second.size() != 4 || dwo.conv.paddings.size() != 4) continue;
+        const std::vector<int> dpd = pad4(dwo.conv.paddings);
+        if (it == shape.end() || it->second.size() != 4 || dpd.size() != 4 || !dwo.conv.padding_algorithm.empty()) continue;
         d.n = static_cast<int>(it->second[0]); d.cin = static_cast<int>(it->second[1]);
         d.h = static_cast<int>(it->second[2]); d.w = static_cast<int>(it->second[3]);
         d.cout = static_cast<int>(dwo.w_dims[0]); d.kh = static_cast<int>(dwo.w_dims[2]); d.kw = static_cast<int>(dwo.w_dims[3]);
-        for (int q = 0; q < 4; ++q) d.pad[q] = dwo.conv.paddings[q];
+        for (int q = 0; q < 4; ++q) d.pad[q] = dpd[q];
         d.stride[0] = dwo.conv.strides[0]; d.stride[1] = dwo.conv.strides[1];
         d.dil[0] = dwo.conv.dilations[0]; d.dil[1] = dwo.conv.dilations[1];
         d.groups = dwo.conv.groups;
@@ -263,6 +269,39 @@ void GraphBuilder::FuseSteps(std::vector<Step>* steps_io) {
       }
     }
   }
+  // (F) a calib[fp32_to_int8] whose only reader is a conv2d that quantises while it stages its rows (plhip_conv2d_calib_supported:
+  // the 3x3 stride-2 stem) is taken over by that conv: the head of the MobileNet programs, the int8 image is never written
+  if (fuse_dwpw_ == 2) {
+    for (size_t i = 0; i < st.size(); ++i) {
+      if (dead[i] || st[i].kind != "calib_f2i" || uses(st[i].out) != 1) continue;
+      int j = -1;
+      for (size_t t = 0; t < st.size(); ++t)
+        if (!dead[t] && st[t].kind == "op" && !st[t].op_inputs.empty() && st[t].op_inputs[0] == st[i].out) j = static_cast<int>(t);
+      if (j < 0) continue;
+      const GraphOp& c = ops_[st[j].op];
+      const std::vector<int> cpd = pad4(c.conv.paddings);
+      if (c.type != "conv2d" || !c.enable_int8 || c.w_dims.size() != 4 || cpd.size() != 4 || c.conv.strides.size() != 2 ||
+          c.conv.dilations.size() != 2 || !c.conv.padding_algorithm.empty() || !st[j].res.empty() || !st[j].calib_out.empty() ||
+          st[j].pw_op >= 0)
+        continue;
+      auto it = shape.find(st[i].in);
+      if (it == shape.end() || it->second.size() != 4) continue;
+      plhip_conv_desc d;
+      memset(&d, 0, sizeof(d));
+      d.n = static_cast<int>(it->second[0]); d.cin = static_cast<int>(it->second[1]);
+      d.h = static_cast<int>(it->second[2]); d.w = static_cast<int>(it->second[3]);
+      d.cout = static_cast<int>(c.w_dims[0]); d.kh = static_cast<int>(c.w_dims[2]); d.kw = static_cast<int>(c.w_dims[3]);
+      for (int q = 0; q < 4; ++q) d.pad[q] = cpd[q];
+      d.stride[0] = c.conv.strides[0]; d.stride[1] = c.conv.strides[1];
+      d.dil[0] = c.conv.dilations[0]; d.dil[1] = c.conv.dilations[1];
+      d.groups = c.conv.groups;
+      if (!plhip_conv2d_calib_supported(&d)) continue;
+      st[j].in_calib_scale = st[i].scale;
+      st[j].via_in = st[i].out;
+      st[j].op_inputs[0] = st[i].in;
+      dead[i] = true;
+    }
+  }
   std::vector<Step> kept;
   for (size_t i = 0; i < st.size(); ++i)
     if (!dead[i]) kept.push_back(st[i]);
@@ -291,6 +330,10 @@ std::vector<std::string> GraphBuilder::Plan() {
       if (op.enable_int8 && s.int8_out) {
         snprintf(buf, sizeof buf, " oscale=%.9g", s.out_scale);
         l += buf;
+      }
+      if (s.in_calib_scale > 0.f) {
+        snprintf(buf, sizeof buf, " in_scale=%.9g", s.in_calib_scale);
+        l += " +calib_in=" + s.via_in + buf;
       }
       if (!s.res.empty()) l += std::string(" +add=") + s.res + (s.res_relu ? " +relu" : "");
       if (!s.calib_out.empty()) {
@@ -347,6 +390,7 @@ std::vector<std::string> GraphBuilder::Lower(HipPredictor* pred) {
         a.calib_out = s.calib_out;
         a.calib_scale = s.calib_scale;
         a.drop_fp32 = s.drop_f32;
+        a.in_calib_scale = s.in_calib_scale;
         if (s.pw_op >= 0) {
           const GraphOp& c = ops_[s.pw_op];
           a.pw_w = c.w.data();

@@ -89,6 +89,8 @@ class GraphBuilder {
     std::string via;          // name the depthwise result would have had
     bool pw_pool{false};      // ... and that conv's sole consumer, a global average pool2d, too (E): `out` is the pool's output
     std::string via_pw;       // name the 1x1 conv's result would have had
+    float in_calib_scale{0.f};  // conv that took the calib[fp32_to_int8] in front of it over (F): its input is the calib's fp32 input
+    std::string via_in;       // name the calib's int8 result would have had
   };
   std::vector<Step> Schedule();
   void FuseSteps(std::vector<Step>* steps);

@@ -79,7 +79,7 @@ void HipPredictor::AddConv(const std::string& op_type, const std::string& in, co
   auto op = std::make_shared<operators::ConvOpLite>(op_type);
   auto& p = op->mutable_param();
   kernels::hip::HipConvFusion fz;  // this target's graph-level fusion state (lite/kernels/hip/conv_fusion.h)
-  const bool fused = !a.calib_out.empty() || !a.residual.empty() || a.pw_w != nullptr;
+  const bool fused = !a.calib_out.empty() || !a.residual.empty() || a.pw_w != nullptr || a.in_calib_scale > 0.f;
   size_t wn = 1;
   for (auto d : w_dims) wn *= static_cast<size_t>(d);
   p.x = Var(in);
@@ -137,6 +137,7 @@ void HipPredictor::AddConv(const std::string& op_type, const std::string& in, co
       op->set_output_pooled();
     }
   }
+  if (a.in_calib_scale > 0.f) fz.calib_input_scale = a.in_calib_scale;
   op->set_padding_algorithm(a.padding_algorithm);
   auto kernel = PickKernel(op_type, Place(TARGET(kHIP), PRECISION(kInt8)), a.int8_out ? "int8_out" : "fp32_out");
   if (fused) {  // this target's fusion state goes to the kernel object, not into the reference's ConvParam (conv_fusion.h)

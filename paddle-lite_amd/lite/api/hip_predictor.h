@@ -45,6 +45,7 @@ struct ConvAttrs {
   int pw_act{0};
   float pw_act_coef{0.f};
   bool pw_pool{false};  // ... and the global average pool2d behind it: `out` is the pool's output, [n, cout, 1, 1] fp32
+  float in_calib_scale{0.f};  // kHIP: the calib[fp32_to_int8] in front taken over: `in` of AddConv is the calib's fp32 input (0 = none)
 };
 
 class HipPredictor {

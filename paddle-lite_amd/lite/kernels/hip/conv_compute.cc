@@ -99,6 +99,13 @@ void ConvCompute<Ptype, OutType>::ReInitWhenNeeded() {
     }
   }
   workspace_bytes_ = is_depthwise_ ? 0 : plhip_conv_workspace_bytes(&desc_);
+  calib_in_fused_ = false;
+  if (fusion_.calib_input_scale > 0.f) {
+    CHECK(!is_depthwise_ && !has_pw_ && !param.fuse_residual_connection && fusion_.calib_output == nullptr)
+        << "kHIP: a conv that took the calib in front of it over has no other fusion";
+    calib_in_fused_ = plhip_conv2d_calib_supported(&desc_) != 0;
+    if (calib_in_fused_) kernel_func_name_ = "calib_fp32_to_int8+" + std::string(plhip_conv_impl_name(&desc_));
+  }
   if (has_pw_) {  // the pointwise conv sees the depthwise conv's output plane (`output` may be the pooled one: from the descriptor)
     pw_desc_.n = desc_.n;
     pw_desc_.h = (desc_.h + desc_.pad[0] + desc_.pad[1] - (desc_.dil[0] * (desc_.kh - 1) + 1)) / desc_.stride[0] + 1;
@@ -246,9 +253,25 @@ void ConvCompute<Ptype, OutType>::Run() {
   auto& param = this->template Param<param_t>();
   auto& ctx = this->ctx_->template As<HIPContext>();
   CHECK(param.x->target() == TARGET(kHIP)) << "conv input must live on the HIP device (io_copy missing?)";
-  const int8_t* x = param.x->template data<int8_t>();
   const float* sc = scale_.data<float>();
   const float* bi = has_bias_ ? bias_.data<float>() : nullptr;
+  const int8_t* x;
+  if (fusion_.calib_input_scale > 0.f) {  // `x` is the fp32 input of the calib this conv took over (fusion F)
+    const float* xf = param.x->template data<float>();
+    if (calib_in_fused_) {
+      void* yo = OutType == PRECISION(kInt8) ? static_cast<void*>(param.output->template mutable_data<int8_t>(TARGET(kHIP)))
+                                             : static_cast<void*>(param.output->template mutable_data<float>(TARGET(kHIP)));
+      HIP_CALL(ctx.ctx(), plhip_conv2d_calib_int8(ctx.ctx(), &desc_, xf, fusion_.calib_input_scale, weights_.raw_data(), sc, bi, yo,
+                                                  OutType == PRECISION(kInt8) ? PLHIP_OUT_I8 : PLHIP_OUT_F32));
+      return;
+    }
+    xq_.Resize(param.x->dims());  // no one-launch form for this shape: the calib into a private tensor, then the conv
+    int8_t* q = xq_.mutable_data<int8_t>(TARGET(kHIP));
+    HIP_CALL(ctx.ctx(), plhip_calib_f32_to_i8(ctx.ctx(), xf, q, fusion_.calib_input_scale, static_cast<int64_t>(param.x->dims().production())));
+    x = q;
+  } else {
+    x = param.x->template data<int8_t>();
+  }
   void* y;
   plhip_out_kind kind;
   if (OutType == PRECISION(kInt8)) {

@@ -50,6 +50,8 @@ class ConvCompute : public KernelLite<TARGET(kHIP), Ptype>, public HipFusableKer
   bool has_pw_{false}, pw_fused_{false}, pw_has_bias_{false};
   plhip_conv_desc pw_desc_{};
   Tensor pw_weights_, pw_scale_, pw_bias_, mid_, mid2_;
+  Tensor xq_;                      // fused calib in front (HipConvFusion::calib_input_scale) on a shape without the one-launch form
+  bool calib_in_fused_{false};
 };
 
 }  // namespace hip

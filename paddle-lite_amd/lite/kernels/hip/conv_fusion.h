@@ -44,6 +44,10 @@ struct HipConvFusion {
   // output [n, cout, 1, 1]; the fused kernel writes the plane average itself (PLHIP_OUT_F32_GAP), other shapes run the
   // instructions one by one inside the kernel object
   bool pw_global_avg_pool{false};
+  // calib[fp32_to_int8] in FRONT of the conv taken over (graph_builder.cc, fusion F): `x` of the ConvParam is then the calib's
+  // fp32 input and this its scale; the kernel quantises while it stages the rows (plhip_conv2d_calib_int8) where it has that
+  // form (the 3x3 stride-2 stem), otherwise the kernel object runs the calib into a private tensor first.  0 = none.
+  float calib_input_scale{0.f};
 };
 
 class HipFusableKernel {

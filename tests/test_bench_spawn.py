@@ -55,6 +55,18 @@ def test_eight_ranks_strong_scaling_ragged_shards():
     assert line["config"]["parallelism"].startswith("batch split x8") and line["value"] > 0 and "MobileNetV2" in line["metric"]
 
 
+def test_a_predictor_far_ahead_of_the_others_does_not_take_their_staging_slots():
+    """Round 4's hang of the N > 1 path: with 4 predictors and 10 staging slots, predictor 0 (no start offset) could run three of
+    its steps (0, 4, 8, 12) before predictor 2 woke up, take the slot step 2 needed (12 % 10), and the coordinator, which issues
+    the collectives in step order, waited for step 2 for ever.  Here every predictor starts 30 ms after the previous one and a
+    step takes ~1 ms: predictor 0 is 12 steps ahead of predictor 2 at once.  The slots are handed on in step order now."""
+    rc, out, err = _run(["--gpus", "2", "--steps", "17", "--warmup", "13", "--inflight", "4", "--batch", "3", "--res", "32", "--windows", "2"],
+                        {"PLHIP_BENCH_STAGGER_US": "30000"}, timeout=240)
+    assert rc == 0, err[-3000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 17 and line["value"] > 0
+
+
 def test_world_size_mismatch_is_an_error():
     rc, out, err = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc == 2 and "WORLD_SIZE=2" in err and out.strip() == ""

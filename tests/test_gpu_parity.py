@@ -266,6 +266,54 @@ def test_stem_mfma_variants(gpu_ctx, pkg, plref):
     assert cnt == 7
 
 
+def test_stem_with_the_calib_in_front(gpu_ctx, pkg, plref):
+    """plhip_conv2d_calib_int8 = calib[fp32_to_int8] + conv 3x3 s2 (Cin <= 3) in one launch (conv_stem_f32in.hip): bit-identical to
+    the oracle's calib followed by its conv: accumulators, int8 and fp32 outputs; values on the rounding ties and beyond the
+    saturation bound in the image; two column tiles, OH % 4 != 0, top padding 0, Cout tails; shapes without the form refused."""
+    import ctypes
+    rng = np.random.default_rng(141)
+    capi = pkg.capi
+    cnt = 0
+    for (n, cin, h, w, cout, pads) in [(2, 3, 224, 224, 32, (1, 1, 1, 1)), (1, 3, 16, 16, 32, (1, 1, 1, 1)), (3, 1, 18, 32, 8, (1, 1, 1, 1)),
+                                       (1, 3, 21, 264, 64, (1, 1, 1, 1)), (2, 2, 10, 8, 33, (0, 1, 1, 0)), (1, 3, 66, 520, 40, (1, 0, 1, 1))]:
+        act = (1, 0, 2, 4)[cnt % 4]
+        alpha = 6.0 if act == 2 else 0.2
+        calib_scale = np.float32(1.0 / 127 * (1 + cnt % 3))
+        xf = rng.uniform(-1.2, 1.2, (n, cin, h, w)).astype(np.float32) * np.float32(1 + cnt % 3)
+        # exact ties (k + 0.5) * scale, values past +-127 * scale and zeros
+        k = rng.integers(-140, 141, xf.size // 7).astype(np.float32)
+        flat = xf.reshape(-1)
+        flat[:k.size] = (k + np.float32(0.5)) * calib_scale
+        flat[k.size:k.size + 16] = 0.0
+        x = plref.calib_f32_to_i8(xf, float(calib_scale))
+        wt = rng.integers(-127, 128, (cout, cin, 3, 3)).astype(np.int8)
+        bias = rng.uniform(-1, 1, cout).astype(np.float32) if cnt % 2 == 0 else None
+        w_scale = ((1 + np.arange(cout) % 7) / 127.0 / 4.0).astype(np.float32)
+        out_scale = cin * 9 / 127.0 if act != 2 else alpha / 127.0
+        s = plref.shape(n, cin, h, w, cout, 3, 3, pads, (2, 2), (1, 1), 1)
+        acc_ref = plref.conv2d_acc(s, x, wt)
+        d = capi.conv_desc(n, cin, h, w, cout, 3, 3, pads, (2, 2), (1, 1), 1, act, alpha)
+        assert gpu_ctx.L.plhip_conv2d_calib_supported(ctypes.byref(d)) == 1
+        acc = gpu_ctx.conv2d_calib(d, xf, float(calib_scale), wt, None, None, capi.OUT_I32)
+        assert np.array_equal(acc, acc_ref), "int32 accumulators differ (%d of %d)" % ((acc != acc_ref).sum(), acc.size)
+        for int8_out, kind in ((0, capi.OUT_F32), (1, capi.OUT_I8)):
+            sc, bi, al = plref.fold_scales(int8_out, float(calib_scale), w_scale, out_scale, bias, cout, act, alpha)
+            d.act_alpha = al
+            y_ref = plref.epilogue(acc_ref, sc, bi, act, al, bool(int8_out))
+            y = gpu_ctx.conv2d_calib(d, xf, float(calib_scale), wt, sc, bi if bias is not None else None, kind)
+            if int8_out:
+                assert np.array_equal(y, y_ref), "int8 output differs"
+            else:
+                np.testing.assert_allclose(y, y_ref, rtol=FP32_RTOL, atol=1e-6)
+        cnt += 1
+    # no one-launch form: left padding 0 / 2, W % 4 != 0, OW % 4 != 0, Cin = 4, stride 1, 7x7
+    for (cin, h, w, k, st, pads) in [(3, 16, 16, 3, 2, (1, 1, 0, 1)), (3, 16, 16, 3, 2, (1, 1, 2, 2)), (3, 16, 18, 3, 2, (1, 1, 1, 1)),
+                                     (3, 16, 20, 3, 2, (1, 1, 1, 1)), (4, 16, 16, 3, 2, (1, 1, 1, 1)), (3, 16, 16, 3, 1, (1, 1, 1, 1)),
+                                     (3, 32, 32, 7, 2, (3, 3, 3, 3))]:
+        d = capi.conv_desc(1, cin, h, w, 16, k, k, pads, (st, st), (1, 1), 1, 1, 0.0)
+        assert gpu_ctx.L.plhip_conv2d_calib_supported(ctypes.byref(d)) == 0, (cin, h, w, k, st, pads)
+
+
 def test_dw_fast_fetch_and_staging(gpu_ctx, pkg, plref):
     """depthwise 3x3 direct kernel: fast row fetch (pad <= 1, RS | OH) against the general fetch (pad 2, ragged OH), LDS
     output staging for narrow planes with even / odd OW, partial last waves (plane count not a multiple of the wave's

@@ -39,12 +39,15 @@ def test_default_dwpw_fusion_takes_the_pairs_the_fused_kernel_takes(lite, wl):
     for batch in (1, 128):
         off, dflt = _plan(lite, wl, net, batch=batch, fuse=True, fuse_dwpw=False), _plan(lite, wl, net, batch=batch, fuse=True, fuse_dwpw=None)
         fl = [l for l in dflt if "+pw=" in l]
-        assert len(dflt) == len(off) - 14 and len(fl) == 13
+        assert len(dflt) == len(off) - 15 and len(fl) == 13
         assert [l.split(" out=")[1].split(" ")[0] for l in fl] == ["pw%d" % i for i in range(2, 14)] + ["pool"]
         assert [l.split(" via=")[1].split(" ")[0] for l in fl] == ["dw%d" % i for i in range(2, 15)]
         # (E) the last pair also takes the global average pool behind it (PLHIP_OUT_F32_GAP): pw14's plane is never written
         assert fl[-1].endswith("+pw=conv2d/fp32_out via=dw14 +pool=avg/global pw_out=pw14") and not any(l.startswith("pool2d/") for l in dflt)
         assert sum("+pool=" in l for l in dflt) == 1
+        # (F) the stem conv takes the calib[fp32_to_int8] in front of it (plhip_conv2d_calib_int8): the int8 image is never written
+        assert dflt[1].startswith("conv2d/int8_out in=image/target_trans out=conv1 ") and "+calib_in=image/precision_trans in_scale=" in dflt[1]
+        assert off[1].startswith("calib/fp32_to_int8 in=image/target_trans out=image/precision_trans") and len(dflt) == 19
     n192 = wl.mobilenet_v1_net(res=192)
     assert not any("+pw=" in l for l in _plan(lite, wl, n192, fuse=True, fuse_dwpw=None))
     forced = _plan(lite, wl, n192, fuse=True, fuse_dwpw=True)

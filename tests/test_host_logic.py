@@ -178,3 +178,19 @@ def test_fused_dwpw_support_query_is_host_only(pkg):
     assert q(128, 64, 112, 2, 64) == 0 and q(128, 128, 56, 2, 128) == 0 and q(128, 256, 28, 2, 256) == 0 and q(8, 64, 56, 2, 128) == 0
     assert q(128, 512, 14, 2, 512) == 0 and q(128, 512, 14, 1, 1024) == 0 and q(128, 192, 14, 1, 256) == 0 and q(128, 640, 14, 1, 512) == 0
     assert q(128, 512, 14, 1, 512, k=5) == 0 and q(128, 512, 14, 1, 512, dil=2) == 0 and q(128, 512, 14, 1, 512, groups=1) == 0
+
+
+def test_calib_conv_support_query_is_host_only(pkg):
+    """plhip_conv2d_calib_supported (calib[fp32_to_int8] + conv in one launch) is a pure function of the descriptor: the 3x3
+    stride-2 stem with Cin <= 3, left padding 1, top padding <= 1, W % 4 == 0 and OW % 4 == 0; everything else is refused (the
+    builder then keeps the two instructions)."""
+    capi = pkg.capi
+    lib = capi.load()
+
+    def q(cin, h, w, k=3, s=2, pads=(1, 1, 1, 1), cout=32, groups=1):
+        d = capi.conv_desc(4, cin, h, w, cout, k, k, pads, (s, s), (1, 1), groups, capi.ACT_RELU, 0.0)
+        return lib.plhip_conv2d_calib_supported(ctypes.byref(d))
+
+    assert q(3, 224, 224) == 1 and q(1, 64, 64) == 1 and q(3, 64, 64, pads=(0, 1, 1, 0)) == 1 and q(3, 224, 224, cout=40) == 1
+    assert q(4, 224, 224) == 0 and q(3, 224, 224, s=1) == 0 and q(3, 224, 224, k=7, pads=(3, 3, 3, 3)) == 0
+    assert q(3, 224, 224, pads=(1, 1, 0, 1)) == 0 and q(3, 224, 226) == 0 and q(3, 224, 228) == 0 and q(3, 224, 224, pads=(2, 2, 1, 1)) == 0
