@@ -76,4 +76,5 @@ for f in ("bench.json", "bench_driver_form.json", "bench_inflight1.json", "bench
     d = g(f)
     print("%-24s %9.1f img/s  %.4f ms/step  roofline.frac %.4f" % (f, d["value"], d["ms_per_step"], d["roofline"]["frac"]))
 print(open(os.path.join(P, "%s_final_opbench.txt" % tag)).read().splitlines()[-1])
-print(json.dumps(json.load(open(os.path.join(P, "pmc_traffic.json")))["pointwise1x1"]))
+_t = json.load(open(os.path.join(P, "pmc_traffic.json")))
+print(json.dumps({k: _t[k] for k in ("dwpw_fused", "stem_conv", "pointwise1x1") if k in _t}))
