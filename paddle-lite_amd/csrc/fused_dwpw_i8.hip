@@ -518,7 +518,8 @@ bool fused_dwpw_plan(FusedArgs* a, int kh, int kw, int sh, int sw, int dh, int d
   a->ones = 0x01010101u;
   a->stream = 0;
   const int fs = knob("FUSED_STREAM", 1);  // 1: every shape of the streaming kernel, 2: stride 1 only, 3: not the 14-wide plane, 0: off
-  if (fs && (sh == 1 || fs != 2) && !(fs == 3 && a->ow == 14) && fused_stream_supported(*a)) {  // the large planes: fused_dwpw_stream.hip
+  // (the plane average as output, OUT_GAP, exists on the small-plane kernel only: nothing else may accept it)
+  if (out != OUT_GAP && fs && (sh == 1 || fs != 2) && !(fs == 3 && a->ow == 14) && fused_stream_supported(*a)) {  // the large planes: fused_dwpw_stream.hip
     a->stream = 1;
     return true;
   }

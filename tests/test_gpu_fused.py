@@ -126,6 +126,10 @@ def test_fused_pair_with_the_global_average_as_output(gpu_ctx, pkg, plref):
     d14 = capi.conv_desc(2, 512, 14, 14, 512, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 512, 1, 0.0)
     assert gpu_ctx.L.plhip_dwpw_fused_supported(ctypes.byref(d14), 512, capi.OUT_F32_GAP) == 0
     assert gpu_ctx.L.plhip_dwpw_fused_supported(ctypes.byref(d14), 512, capi.OUT_F32) == 1
+    for (c, hw, st, m) in [(128, 56, 1, 128), (256, 28, 1, 256), (256, 28, 2, 512), (64, 112, 2, 128)]:  # the streaming kernel's shapes
+        dd = capi.conv_desc(2, c, hw, hw, c, 3, 3, (1, 1, 1, 1), (st, st), (1, 1), c, 1, 0.0)
+        assert gpu_ctx.L.plhip_dwpw_fused_supported(ctypes.byref(dd), m, capi.OUT_F32_GAP) == 0, (c, hw, st, m)
+        assert gpu_ctx.L.plhip_dwpw_fused_supported(ctypes.byref(dd), m, capi.OUT_F32) == 1, (c, hw, st, m)
 
 
 def test_fused_unsupported_shapes_are_reported(gpu_ctx, pkg):

@@ -169,8 +169,11 @@ def test_fused_dwpw_support_query_is_host_only(pkg):
     for (c, hw, m) in [(32, 112, 64), (128, 56, 128), (256, 28, 256)]:
         for out in (capi.OUT_I8, capi.OUT_F32, capi.OUT_I32):
             assert q(128, c, hw, 1, m, out=out) == 1 and q(1, c, hw, 1, m, out=out) == 1, (c, hw, m, out)
-    for out in (capi.OUT_I8, capi.OUT_F32, capi.OUT_I32):  # the 7 x 7 planes
+    for out in (capi.OUT_I8, capi.OUT_F32, capi.OUT_I32, capi.OUT_F32_GAP):  # the 7 x 7 planes (also with the plane average as output)
         assert q(128, 1024, 7, 1, 1024, out=out) == 1 and q(1, 512, 14, 2, 1024, out=out) == 1, out
+    # ... which no other kernel has
+    assert q(128, 512, 14, 1, 512, out=capi.OUT_F32_GAP) == 0 and q(128, 128, 56, 1, 128, out=capi.OUT_F32_GAP) == 0
+    assert q(128, 64, 112, 2, 128, out=capi.OUT_F32_GAP) == 0 and q(128, 256, 28, 2, 512, out=capi.OUT_F32_GAP) == 0
     for (c, hw, m) in [(512, 7, 1024), (1024, 7, 512), (64, 112, 128), (32, 112, 32), (128, 28, 128), (256, 56, 256)]:
         assert q(128, c, hw, 1, m) == 0, (c, hw, m)
     for out in (capi.OUT_I8, capi.OUT_F32, capi.OUT_I32):  # stride 2: dw3 / pw3, dw5 / pw5
