@@ -464,3 +464,44 @@ def test_dwpw_fusion_equals_the_oracle_graph(lite, wl, plref, which, batch, mode
         np.testing.assert_allclose(p.get_var(out, np.float32), ref["prob"], rtol=1e-4, atol=1e-7)
     finally:
         p.close()
+
+
+def test_fused_program_with_its_feed_resized_off_the_fused_kernels(lite, wl, plref):
+    """The default program of MobileNetV1 is lowered for 224 x 224 (every pair one launch, the pool and the stem's calib taken over);
+    then the feed is resized to 192 x 192, where NO fused kernel has the planes: every fused instruction must fall back inside its
+    kernel object (ConvCompute::ReInitWhenNeeded: depthwise + 1x1 as two launches through a private tensor, + the global average
+    pool kernel behind the last pair; the stem keeps its one-launch form, 192 % 4 == 0) and still produce the oracle's numbers;
+    back at 224 the first result is reproduced."""
+    net224, net192 = wl.mobilenet_v1_net(), wl.mobilenet_v1_net(res=192)
+    rng = np.random.default_rng(360)
+    img224 = rng.uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+    img192 = rng.uniform(-1, 1, (2, 3, 192, 192)).astype(np.float32)
+    ref224 = graph_oracle.forward(plref, net224, img224)
+    ref192 = graph_oracle.forward(plref, net192, img192)
+    p, out = _run_graph(lite, wl, net224, img224, fuse=True)
+    try:
+        assert sum("+pw=" in l for l in p.graph_plan()) == 13 and any("+pool=" in l for l in p.graph_plan())
+        dev_out = out[:-len("/host")]
+        first = p.get_var(dev_out, np.float32)
+        np.testing.assert_allclose(first, ref224[dev_out], rtol=1e-5, atol=1e-6)
+        p.add_feed(net224["input"], img192.shape, lite.PREC_FLOAT)
+        p.set_input(net224["input"], img192)
+        p.run()
+        names = p.kernel_names()
+        assert sum("conv_depthwise_int8_hip+conv1x1s1" in n for n in names) == 13, names   # every pair fell back
+        assert any("+pooling_global_avg" in n and "conv_depthwise_int8_hip+" in n for n in names), names
+        for v in ("conv1", "pw2", "pw7", "pw13", "pool", dev_out):
+            want = ref192[v]
+            got = p.get_var(v, want.dtype)
+            assert got.shape == want.shape, v
+            if want.dtype == np.int8:
+                assert np.array_equal(got, want), v
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=v)
+        p.add_feed(net224["input"], img224.shape, lite.PREC_FLOAT)
+        p.set_input(net224["input"], img224)
+        p.run()
+        assert np.array_equal(p.get_var(dev_out, np.float32), first)
+        assert sum("conv_depthwise_3x3_pointwise_1x1_fused" in n for n in p.kernel_names()) == 13
+    finally:
+        p.close()
