@@ -314,12 +314,9 @@ __device__ __forceinline__ void stem_mfma_body(const DirectS2Args& a, const int8
       if (OUT != OUT_I32) stage_scale_bias<1, OUT>(g, mt, lane, lsb);
     }
     v16i acc[1][4];
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (an inline operand of the MFMA: no accumulator zeroing)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0;
-      acc[0][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[0][j], 0, 0, 0);
-    }
+    for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], zero16, 0, 0, 0);
     if (qvalid) {
       if (OUT == OUT_I32) {
         gemm_epilogue<1, OUT, true, MFULL, ACT_NONE>(g, acc, mt, h, b, hw, lsb, g.HWY - hw);

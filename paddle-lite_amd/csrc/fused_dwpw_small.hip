@@ -231,14 +231,11 @@ __global__ __launch_bounds__(512, K >= 1024 ? 1 : 2) void fused_dwpw7_kernel(Fus
 
   // ------------------------------------------------------------------ consume
   v16i acc[2][MW];
-#pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][m][r] = 0;
-#pragma unroll 2
-  for (int ks = 0; ks < KS; ks += WD) {
+  const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // one group of WD K-steps; FIRST: its first K-step multiplies into the constant 0 (an inline operand of the MFMA) instead of
+  // accumulators zeroed by 16 v_mov each
+  auto group = [&](int ks, auto first_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value;
 #pragma unroll
     for (int u = 0; u < WD; ++u) {
       const int kk = ks + u;
@@ -254,10 +251,14 @@ __global__ __launch_bounds__(512, K >= 1024 ? 1 : 2) void fused_dwpw7_kernel(Fus
         const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i_ptr_t)(f7_lds + ka + n * 32 + 8 * F7_PITCH));
         const v4i av = {lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
-        for (int m = 0; m < MW; ++m) acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, Wf[u][m], acc[n][m], 0, 0, 0);
+        for (int m = 0; m < MW; ++m)
+          acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, Wf[u][m], (FIRST && u == 0) ? zero16 : acc[n][m], 0, 0, 0);
       }
     }
-  }
+  };
+  group(0, integral_constant<bool, true>{});
+#pragma unroll 2
+  for (int ks = WD; ks < KS; ks += WD) group(ks, integral_constant<bool, false>{});
 
   PLHIP_F7_STAMP(6);
   if (OUT != OUT_I8 && OUT != OUT_GAP) __syncthreads();  // the image is dead: its LDS becomes the output staging of the 4-byte forms

@@ -314,12 +314,9 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
       const uint8_t* const wpk = pass_w(mp);
       const int mt0 = (mp * MSPLIT + ms) * MW;
       v16i acc[NW][MW];
-#pragma unroll
-      for (int n = 0; n < NW; ++n)
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[n][m][r] = 0;
+      // (the first K-step multiplies into the constant 0, an inline operand of the MFMA: zeroing the accumulators first was
+      // 16 v_mov per tile, 110-130 per wave = 4-6 % of everything these kernels issue)
+      const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + WD - 1 < KS) {
@@ -335,7 +332,8 @@ __global__ __launch_bounds__(256, M / MP >= 256 ? 2 : 3) void fused_dwpw_stream_
             const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i_ptr_t)(fs_lds + ka + n * 32 + 8 * FS_PITCH));
             const v4i av = {lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
-            for (int m = 0; m < MW; ++m) acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, Wf[ks % WD][m], acc[n][m], 0, 0, 0);
+            for (int m = 0; m < MW; ++m)
+              acc[n][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, Wf[ks % WD][m], ks == 0 ? zero16 : acc[n][m], 0, 0, 0);
           }
         }
       }
